@@ -1,0 +1,213 @@
+/*
+ * mv2.h — C ABI of libmv2_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * VideoTokenizer encode -> quantize -> decode hot path.
+ *
+ * The reference (lucidrains/magvit2-pytorch) has no FFI / plugin interface: every FLOP is a
+ * stock ATen op reached from Python.  This header is therefore the boundary a
+ * maintainer would bind from `magvit2_pytorch/magvit2_pytorch.py` (ctypes stub shown in
+ * INTEGRATION.md); each entry point names the reference lines whose ATen calls it replaces
+ * (M = magvit2_pytorch/magvit2_pytorch.py, A = magvit2_pytorch/attend.py).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (tensor.data_ptr()) unless the name ends in `_host`;
+ *  - activations are dense channel-last NDHWC: element (b,t,h,w,c) at ((((b*T+t)*H+h)*W+w)*C+c);
+ *    "rows" are the B*T*H*W positions, a row is C contiguous channels;
+ *  - `dtype` selects the storage + MFMA input type of activations and packed weights:
+ *      MV2_BF16  bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate   (fast mode)
+ *      MV2_F32   fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) (id-parity mode)
+ *    biases, norms' statistics, gates, softmax and quantizer arithmetic are fp32 in both;
+ *  - no hidden allocation, no global state, re-entrant per stream: the caller owns all
+ *    buffers, passes workspaces explicitly and gets the launch on `stream` (hipStream_t);
+ *  - return value: 0 on success, a negative MV2_E* code on a rejected argument, or the
+ *    positive hipError_t of a failed launch.  No exceptions cross the ABI.
+ */
+#ifndef MV2_H
+#define MV2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV2_ABI_VERSION 1
+
+enum { MV2_BF16 = 0, MV2_F32 = 1 };
+
+enum {
+    MV2_OK = 0,
+    MV2_EINVAL = -1,      /* malformed descriptor (alignment / divisibility rules below) */
+    MV2_ETOOLARGE = -2,   /* a buffer exceeds the 2^32-byte range of 32-bit buffer offsets */
+    MV2_EWORKSPACE = -3,  /* workspace smaller than mv2_*_workspace_bytes() */
+    MV2_ENODEVICE = -4
+};
+
+/* activation applied in the conv epilogue */
+enum { MV2_ACT_NONE = 0, MV2_ACT_ELU = 1, MV2_ACT_SILU = 2, MV2_ACT_GEGLU = 3 };
+/* store mode of the conv epilogue */
+enum {
+    MV2_STORE_ROWS = 0,      /* out[row][n]                                   dense NDHWC          */
+    MV2_STORE_SHUFFLE = 1,   /* depth-to-space/time: packed column n = q*Cq + c goes to
+                                position (t*rt+qt, h*rh+qh, w*rw+qw), channel c                    */
+    MV2_STORE_NCTHW_F32 = 2  /* fp32 NCTHW video with the first `crop_t` frames dropped            */
+};
+
+int mv2_abi_version(void);
+/* number of compute units of the current device (grid sizing); <0 on error */
+int mv2_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * mv2_conv — implicit-GEMM convolution on MFMA with a fused epilogue.
+ * Replaces: CausalConv3d.forward M:924-928 (F.pad + nn.Conv3d: conv_in M:1557, ResidualUnit k3
+ * M:937, conv_out M:1642), nn.Conv3d 1x1x1 M:939 / M:493-495, SpatialDownsample2x conv M:776,
+ * TimeDownsample2x pad+conv M:802-803, SpatialUpsample2x / TimeUpsample2x conv+SiLU+Rearrange
+ * M:819-825 / M:856-862, nn.Linear to_qkv / to_out M:351-368 and the Taylor-attention linears,
+ * ELU M:938,940, GEGLU M:466-469, Residual add M:174, RMSNorm scaling M:276 (as `rowscale`),
+ * TokenShift M:250-253 (as a two-segment K program).
+ *
+ *   D[n][row] = sum_k Wp[k][n] * A[row][k]       (n = output channel, fp32 accumulate)
+ * K is a host-built program of `nsteps` steps; one step is 128 bytes of a row's K extent
+ * (64 bf16 / 32 fp32 elements) made of 128/seg_bytes equal segments.  Segment s of the program
+ * reads seg_bytes contiguous bytes of the input at
+ *      element offset  rowbase(row) + segs[s].elem_offset ,
+ *      rowbase(b,to,ho,wo) = (((b*Ti + to*st - pt)*Hi + ho*sh - ph)*Wi + wo*sw - pw)*Ci
+ * and contributes zeros when check_bounds != 0 and the tap (it,ih,iw) packed in segs[s].sel
+ * falls outside [0,Ti)x[0,Hi)x[0,Wi) (causal front pad in time, zero "same" pad in space), or
+ * when sel has bit 31 set (filler segment).  sel = 1<<it | 1<<(8+ih) | 1<<(16+iw).
+ * Packed weights Wp: [nsteps][co_pad][128 bytes], row n of step s holds the weights matching
+ * that step's segments, zero in padding rows / columns.  (See magvit2_pytorch_amd/pack.py.)
+ *
+ * Epilogue per output element v (fp32):  v *= rowscale[row] (if given); v += bias[n] (if given);
+ * act; v += residual[row][n] (if given, same dtype/layout as out, MV2_STORE_ROWS only); store.
+ * MV2_ACT_GEGLU: packed columns come in blocks of 64: 32 value columns then their 32 gate
+ * columns; out channel j = 32*blk + i gets gelu(gate) * value and `co` is the number of OUTPUT
+ * channels written (padded hidden width; padding columns have zero weights -> exact zeros).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mv2_seg {
+    int32_t elem_offset;   /* added to rowbase, in elements */
+    uint32_t sel;          /* tap selection bits, see above */
+} mv2_seg;
+
+typedef struct mv2_conv_desc {
+    int32_t dtype;
+    int32_t B, Ti, Hi, Wi, Ci;     /* input geometry; Ci = row length (channel stride) in elements */
+    int32_t To, Ho, Wo;            /* output positions */
+    int32_t co;                    /* valid packed output columns (2*hidden_pad for GEGLU) */
+    int32_t co_pad;                /* rows per step in Wp, multiple of 128 */
+    int32_t st, sh, sw;            /* strides */
+    int32_t pt, ph, pw;            /* leading pads */
+    int32_t kt, kh, kw;            /* taps per axis (<= 8 each), used for the bounds masks */
+    int32_t nsteps;
+    int32_t seg_bytes;             /* 16, 32, 64 or 128 */
+    int32_t check_bounds;
+    int32_t act;                   /* MV2_ACT_*   */
+    int32_t store;                 /* MV2_STORE_* */
+    int32_t rt, rh, rw;            /* MV2_STORE_SHUFFLE factors (1 otherwise) */
+    int32_t crop_t;                /* MV2_STORE_NCTHW_F32: leading frames dropped */
+    int32_t out_c;                 /* channels per output row (row stride of `out`) */
+    int32_t splitk;                /* 0 = let the library choose, >=1 forced */
+} mv2_conv_desc;
+
+size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d);
+int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+             const float* bias, const float* rowscale, const void* residual, void* out,
+             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mv2_video_to_ndhwc — API-edge layout change + zero padding.
+ * Replaces: pad_at_dim M:1537 and conv_in's F.pad M:927 (the 7x7x7 halo is materialised once so
+ * conv_in runs without bounds checks), and the NCTHW -> channel-last rearranges.
+ * in : fp32 NCTHW (B,C,T,H,W).  out: dtype NDHWC (B, T+pad_t, H+2*pad_hw, W+2*pad_hw, c_pad) with
+ * zeros in every padded frame / border / channel; `tail_elems` extra zero elements follow.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_video_to_ndhwc(int dtype, const float* in, void* out, int B, int C, int T, int H, int W,
+                       int pad_t, int pad_hw, int c_pad, int tail_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mv2_rms_rowscale — per-row 1 / max(||x_row||_2, 1e-12)  (fp32), the data-dependent half of
+ * RMSNorm M:275-276 (F.normalize); sqrt(dim)*gamma is folded into the consumer's packed weights.
+ * shift_hw > 0: statistics of the TokenShift-ed row (M:250-253): channels [C/2, C) come from
+ * the row `shift_hw` rows earlier (previous frame) or are zero when (row / shift_hw) % T == 0.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64_t rows, int C, int shift_hw, int T,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SqueezeExcite (M:221-240) in three stream-ordered launches over frames = B*T, P = H*W:
+ *   pool : per frame chunk online-softmax partials of  softmax_p(wk.y_p + bk)  weighted channel sums
+ *          part[(f*nchunk + j)*(C+2)] = {max, sumexp, psum[C]}
+ *   gate : combines the partials, 1x1 MLP (LeakyReLU 0.1) and sigmoid -> gate[f][C] (fp32)
+ *   apply: out = gate[f] * y + residual            (also the Residual add of M:174)
+ * ------------------------------------------------------------------------------------------- */
+int mv2_se_pool(int dtype, const void* y, const float* wk, float bk, float* part, int frames, int P, int C,
+                int nchunk, void* stream);
+int mv2_se_gate(const float* part, const float* w1, const float* b1, const float* w2, const float* b2,
+                float* gate, int frames, int C, int hidden, int nchunk, void* stream);
+int mv2_se_apply(int dtype, const void* y, const float* gate, const void* residual, void* out, int frames,
+                 int P, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mv2_attention — softmax attention with learned memory key/values.
+ * Replaces: Attention.forward M:381-387 (split heads, prepend mem_kv) + Attend.forward A:186-243
+ * (q k^T d^-1/2, right-aligned causal mask A:46-47, softmax, attn v).
+ * qkv: rows x (3*heads*dim_head), column = (which*heads + head)*dim_head + d.
+ * Sequence s, token i lives at row  (s / seq_inner)*seq_outer_stride + (s % seq_inner) + i*tok_stride
+ *   space attention: seq_inner = 1,   seq_outer_stride = n, tok_stride = 1   (s = frame)
+ *   time  attention: seq_inner = H*W, seq_outer_stride = T*H*W, tok_stride = H*W (s = pixel)
+ * mem_kv: fp32 (2, heads, n_mem, dim_head).  out: rows x (heads*dim_head), same row addressing.
+ * dim_head must be 32 (the reference default, M:1076).
+ * ------------------------------------------------------------------------------------------- */
+int mv2_attention(int dtype, const void* qkv, const float* mem_kv, void* out, int nseq, int n, int heads,
+                  int dim_head, int n_mem, int causal, int seq_inner, int64_t seq_outer_stride,
+                  int64_t tok_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Taylor-series linear attention (third-party TaylorSeriesLinearAttn, call site M:430), dim_head 8.
+ *   kv   : per (frame, chunk, head) partial sums over tokens of phi(k)^T [v, 1]  -> part (fp32)
+ *          part[((f*nchunk + j)*heads + h)*657], 657 = 73*9
+ *   apply: reduces the chunks, out = phi(q * d^-1/2) . KV / max(phi(q) . Ksum, 1e-5)
+ * q: rows x (heads*8); kv: rows x (2*heads*8) with k first; out: rows x (heads*8).
+ * ------------------------------------------------------------------------------------------- */
+int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames, int n, int heads, int nchunk,
+                  void* stream);
+int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames,
+                     int n, int heads, int nchunk, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quantizers (third-party vector_quantize_pytorch; call sites M:1574, M:1593, M:1700, M:1705).
+ * One wavefront per token; the per-token reductions are wave shuffles.
+ *  mv2_lfq : z = W_in x + b_in ; z = tanh(z/clamp)*clamp (clamp <= 0: skipped);
+ *            bit_i = z_i > 0 ; ids[c] = sum_i bit_i << (cb_dim-1-i)  (int64, per codebook c);
+ *            quantized = W_out (+-scale) + b_out.  prequant (optional, may be NULL): z (fp32).
+ *  mv2_fsq : bounded = tanh(z + shift)*half_l - offset ; r = rint(bounded); code = r / half_w;
+ *            ids[c] = sum_i (r_i + half_w_i) * basis_i (int32).
+ *  *_codes : ids -> codes -> W_out codes + b_out   (indices_to_codes, M:1593).
+ * W_in: (cb_total, C) fp32, W_out: (C, cb_total) fp32, cb_total = cb_dim * num_codebooks <= 32.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out,
+            const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
+            int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out, const float* b_out, void* out,
+                  int64_t rows, int C, int cb_dim, int num_codebooks, float scale, void* stream);
+int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out,
+            const float* b_out, const float* shift, const float* half_l, const float* offset,
+            const float* half_w, const int32_t* basis, void* quantized, int32_t* ids, float* prequant,
+            int64_t rows, int C, int cb_dim, int num_codebooks, void* stream);
+int mv2_fsq_codes(int dtype, const int32_t* ids, const float* w_out, const float* b_out,
+                  const int32_t* levels, const float* half_w, const int32_t* basis, void* out, int64_t rows,
+                  int C, int cb_dim, int num_codebooks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Timing helper for bench.py: HIP events on the stream the kernels are launched on.
+ * ------------------------------------------------------------------------------------------- */
+void* mv2_event_create(void);
+int mv2_event_record(void* ev, void* stream);
+int mv2_event_sync(void* ev);
+float mv2_event_elapsed_ms(void* start, void* stop);
+void mv2_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MV2_H */

@@ -1,0 +1,282 @@
+// Bandwidth-bound kernels of the hot path: API-edge layout change, RMSNorm statistics and the
+// three SqueezeExcite passes.  All loads/stores are 16-byte vectors on NDHWC rows.
+#include "common.h"
+
+// --------------------------------------------------------------------------- video -> padded NDHWC
+template <typename E>
+__global__ __launch_bounds__(256) void video_to_ndhwc_kernel(const float* __restrict__ in, typename E::T* __restrict__ out,
+                                                             int B, int C, int T, int H, int W, int pad_t, int pad_hw,
+                                                             int c_pad, int64_t npix, int64_t tail) {
+    const int Tp = T + pad_t, Hp = H + 2 * pad_hw, Wp = W + 2 * pad_hw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix + tail; i += stride) {
+        if (i >= npix) {   // zero tail (read slack for the merged (dw, c) K segments of conv_in)
+            for (int c = 0; c < c_pad; ++c) st_elem<E>(out, npix * c_pad + (i - npix) * c_pad + c, 0.f);
+            continue;
+        }
+        const int w = (int)(i % Wp); int64_t r = i / Wp;
+        const int h = (int)(r % Hp); r /= Hp;
+        const int t = (int)(r % Tp); const int b = (int)(r / Tp);
+        const int ti = t - pad_t, hi = h - pad_hw, wi = w - pad_hw;
+        const bool inside = ti >= 0 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        for (int c = 0; c < c_pad; ++c) {
+            float v = 0.f;
+            if (inside && c < C) v = in[(((int64_t)b * C + c) * T + ti) * ((int64_t)H * W) + (int64_t)hi * W + wi];
+            st_elem<E>(out, i * c_pad + c, v);
+        }
+    }
+}
+
+extern "C" int mv2_video_to_ndhwc(int dtype, const float* in, void* out, int B, int C, int T, int H, int W,
+                                  int pad_t, int pad_hw, int c_pad, int tail_elems, void* stream) {
+    if (!in || !out || c_pad < C || B <= 0 || tail_elems % c_pad != 0) return MV2_EINVAL;
+    const int64_t npix = (int64_t)B * (T + pad_t) * (H + 2 * pad_hw) * (W + 2 * pad_hw);
+    const int64_t tail = tail_elems / c_pad;
+    int64_t blocks = (npix + tail + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV2_BF16)
+        hipLaunchKernelGGL((video_to_ndhwc_kernel<BF16>), dim3((unsigned)blocks), dim3(256), 0, st, in, (unsigned short*)out, B, C, T, H, W, pad_t, pad_hw, c_pad, npix, tail);
+    else if (dtype == MV2_F32)
+        hipLaunchKernelGGL((video_to_ndhwc_kernel<F32>), dim3((unsigned)blocks), dim3(256), 0, st, in, (float*)out, B, C, T, H, W, pad_t, pad_hw, c_pad, npix, tail);
+    else return MV2_EINVAL;
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// --------------------------------------------------------------------------- RMSNorm statistics
+// G lanes cooperate on one row (G = min(64, chunks per row), power of two); lane reads chunks
+// lane, lane+G, ... ; sum of squares reduced with xor shuffles inside the group.
+template <typename E>
+__global__ __launch_bounds__(256) void rms_rowscale_kernel(const void* __restrict__ x, float* __restrict__ rs, int64_t rows,
+                                                           int C, int G, int shift_hw, int T) {
+    const int nchunk = C / E::kVec;
+    const int rows_per_block = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + g; row < rows; row += (int64_t)gridDim.x * rows_per_block) {
+        float ss = 0.f;
+        bool prev_ok = true;
+        if (shift_hw > 0) prev_ok = ((row / shift_hw) % T) > 0;
+        for (int ch = l; ch < nchunk; ch += G) {
+            int64_t src = row;
+            bool zero = false;
+            if (shift_hw > 0 && ch * E::kVec >= C / 2) { src = row - shift_hw; zero = !prev_ok; }
+            if (!zero) {
+                const i32x4 v = *(const i32x4*)((const char*)x + (src * C + (int64_t)ch * E::kVec) * E::kBytes);
+                float f[8]; Chunk<E>::unpack(v, f);
+#pragma unroll
+                for (int j = 0; j < E::kVec; ++j) ss += f[j] * f[j];
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (l == 0) rs[row] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    }
+}
+
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64_t rows, int C, int shift_hw, int T, void* stream) {
+    if (!x || !rowscale || rows <= 0) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (C % kvec != 0 || (shift_hw > 0 && (C / 2) % kvec != 0)) return MV2_EINVAL;
+    const int nchunk = C / kvec;
+    int G = nchunk >= 64 ? 64 : nchunk;
+    if (!is_pow2(G) || (nchunk > 64 && nchunk % 64 != 0)) return MV2_EINVAL;
+    const int rpb = 256 / G;
+    int64_t blocks = (rows + rpb - 1) / rpb; if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((rms_rowscale_kernel<BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, rowscale, rows, C, G, shift_hw, T);
+    else if (dtype == MV2_F32) hipLaunchKernelGGL((rms_rowscale_kernel<F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, rowscale, rows, C, G, shift_hw, T);
+    else return MV2_EINVAL;
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// --------------------------------------------------------------------------- SqueezeExcite: pool
+// grid (nchunk, frames).  A block streams its slice of the frame's P rows once; each row slot keeps
+// an online-softmax state (running max, sum of exp, exp-weighted channel sums) in registers; the
+// slots are merged through LDS at the end.
+template <typename E, int NV>
+__global__ __launch_bounds__(256) void se_pool_kernel(const void* __restrict__ y, const float* __restrict__ wk, float bk,
+                                                      float* __restrict__ part, int P, int C, int G, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KV = E::kVec;
+    const int f = blockIdx.y, j = blockIdx.x;
+    const int R = 256 / G;                      // row slots per block
+    const int slot = threadIdx.x / G, l = threadIdx.x % G;
+    const int rows_per_chunk = (P + nchunk - 1) / nchunk;
+    const int p_begin = j * rows_per_chunk, p_end = min(P, p_begin + rows_per_chunk);
+
+    float wreg[NV][KV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) wreg[v][k] = wk[(l + v * G) * KV + k];
+
+    float m_run = -INFINITY, s_run = 0.f;
+    float acc[NV][KV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) acc[v][k] = 0.f;
+
+    const char* base = (const char*)y + ((int64_t)f * P) * C * E::kBytes;
+    for (int p = p_begin + slot; p < p_end; p += R) {
+        float xv[NV][KV];
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const i32x4 q = *(const i32x4*)(base + ((int64_t)p * C + (int64_t)(l + v * G) * KV) * E::kBytes);
+            Chunk<E>::unpack(q, xv[v]);
+#pragma unroll
+            for (int k = 0; k < KV; ++k) dot += xv[v][k] * wreg[v][k];
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        const float logit = dot + bk;
+        const float m_new = fmaxf(m_run, logit);
+        const float sc = expf(m_run - m_new);      // exp(-inf) = 0 on the first row
+        const float e = expf(logit - m_new);
+        s_run = s_run * sc + e;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < KV; ++k) acc[v][k] = acc[v][k] * sc + e * xv[v][k];
+        m_run = m_new;
+    }
+    // merge the R slots: sm[slot*(C+2)] = {m, s, acc[C]}
+    float* mine = sm + slot * (C + 2);
+    if (l == 0) { mine[0] = m_run; mine[1] = s_run; }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) mine[2 + (l + v * G) * KV + k] = acc[v][k];
+    __syncthreads();
+    float M = -INFINITY;
+    for (int r = 0; r < R; ++r) M = fmaxf(M, sm[r * (C + 2)]);
+    float* dst = part + ((int64_t)f * nchunk + j) * (C + 2);
+    for (int c = threadIdx.x; c < C + 2; c += 256) {
+        float o;
+        if (c == 0) o = M;
+        else {
+            o = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float mr = sm[r * (C + 2)];
+                const float w = (mr == -INFINITY) ? 0.f : expf(mr - M);
+                o += sm[r * (C + 2) + c] * w;
+            }
+        }
+        dst[c] = o;
+    }
+}
+
+extern "C" int mv2_se_pool(int dtype, const void* y, const float* wk, float bk, float* part, int frames, int P, int C,
+                           int nchunk, void* stream) {
+    if (!y || !wk || !part || frames <= 0 || P <= 0 || nchunk <= 0 || nchunk > P) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    if (C % kvec != 0) return MV2_EINVAL;
+    const int nch = C / kvec;
+    int G = nch >= 64 ? 64 : nch;
+    if (!is_pow2(G) || (nch > 64 && nch % 64 != 0)) return MV2_EINVAL;
+    const int NV = nch / G;
+    if (NV != 1 && NV != 2 && NV != 4) return MV2_EINVAL;
+    const size_t lds = (size_t)(256 / G) * (C + 2) * sizeof(float);
+    if (lds > 64 * 1024) return MV2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nchunk, (unsigned)frames);
+#define SE_POOL(EE, NVV) hipLaunchKernelGGL((se_pool_kernel<EE, NVV>), grid, dim3(256), lds, st, y, wk, bk, part, P, C, G, nchunk)
+    if (dtype == MV2_BF16) { if (NV == 1) SE_POOL(BF16, 1); else if (NV == 2) SE_POOL(BF16, 2); else SE_POOL(BF16, 4); }
+    else { if (NV == 1) SE_POOL(F32, 1); else if (NV == 2) SE_POOL(F32, 2); else SE_POOL(F32, 4); }
+#undef SE_POOL
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// --------------------------------------------------------------------------- SqueezeExcite: gate
+// one block per frame: merge chunk partials -> pooled[C]; hidden = lrelu(W1 pooled + b1);
+// gate = sigmoid(W2 hidden + b2).  One wave per output unit, lanes stride the reduction.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                      int hidden, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pooled = sm;            // C
+    float* hid = sm + C;           // hidden
+    const int f = blockIdx.x;
+    const float* pf = part + (int64_t)f * nchunk * (C + 2);
+    float M = -INFINITY;
+    for (int j = 0; j < nchunk; ++j) M = fmaxf(M, pf[j * (C + 2)]);
+    float S = 0.f;
+    for (int j = 0; j < nchunk; ++j) S += pf[j * (C + 2) + 1] * expf(pf[j * (C + 2)] - M);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < nchunk; ++j) a += pf[j * (C + 2) + 2 + c] * expf(pf[j * (C + 2)] - M);
+        pooled[c] = a / S;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < hidden; k += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += w1[(int64_t)k * C + c] * pooled[c];
+        a = wave_sum(a);
+        if (lane == 0) { a += b1[k]; hid[k] = a > 0.f ? a : 0.1f * a; }
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        float a = 0.f;
+        for (int k = lane; k < hidden; k += 64) a += w2[(int64_t)c * hidden + k] * hid[k];
+        a = wave_sum(a);
+        if (lane == 0) { a += b2[c]; gate[(int64_t)f * C + c] = 1.f / (1.f + expf(-a)); }
+    }
+}
+
+extern "C" int mv2_se_gate(const float* part, const float* w1, const float* b1, const float* w2, const float* b2,
+                           float* gate, int frames, int C, int hidden, int nchunk, void* stream) {
+    if (!part || !w1 || !b1 || !w2 || !b2 || !gate || frames <= 0) return MV2_EINVAL;
+    const size_t lds = (size_t)(C + hidden) * sizeof(float);
+    if (lds > 64 * 1024) return MV2_EINVAL;
+    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)frames), dim3(256), lds, (hipStream_t)stream, part, w1, b1, w2, b2, gate, C, hidden, nchunk);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// --------------------------------------------------------------------------- SqueezeExcite: apply
+template <typename E>
+__global__ __launch_bounds__(256) void se_apply_kernel(const void* __restrict__ y, const float* __restrict__ gate,
+                                                       const void* __restrict__ res, void* __restrict__ out, int64_t nchunks,
+                                                       int P, int C) {
+    const int cpr = C / E::kVec;   // chunks per row
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c0 = (int)(i - row * cpr) * E::kVec;
+        const int64_t f = row / P;
+        const i32x4 yv = ((const i32x4*)y)[i];
+        float a[8], r[8];
+        Chunk<E>::unpack(yv, a);
+        const float* g = gate + f * C + c0;
+        if (res) { const i32x4 rv = ((const i32x4*)res)[i]; Chunk<E>::unpack(rv, r); }
+#pragma unroll
+        for (int k = 0; k < E::kVec; ++k) a[k] = a[k] * g[k] + (res ? r[k] : 0.f);
+        ((i32x4*)out)[i] = Chunk<E>::pack(a);
+    }
+}
+
+extern "C" int mv2_se_apply(int dtype, const void* y, const float* gate, const void* residual, void* out, int frames,
+                            int P, int C, void* stream) {
+    if (!y || !gate || !out || frames <= 0 || P <= 0) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if ((dtype != MV2_BF16 && dtype != MV2_F32) || C % kvec != 0) return MV2_EINVAL;
+    const int64_t nchunks = (int64_t)frames * P * (C / kvec);
+    int64_t blocks = (nchunks + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((se_apply_kernel<BF16>), dim3((unsigned)blocks), dim3(256), 0, st, y, gate, residual, out, nchunks, P, C);
+    else hipLaunchKernelGGL((se_apply_kernel<F32>), dim3((unsigned)blocks), dim3(256), 0, st, y, gate, residual, out, nchunks, P, C);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// --------------------------------------------------------------------------- timing helpers
+extern "C" void* mv2_event_create(void) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void*)e; }
+extern "C" int mv2_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+extern "C" int mv2_event_sync(void* ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
+extern "C" float mv2_event_elapsed_ms(void* a, void* b) { float ms = -1.f; if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f; return ms; }
+extern "C" void mv2_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }

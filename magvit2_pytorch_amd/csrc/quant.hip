@@ -1,0 +1,221 @@
+// LFQ / FSQ quantizers: one wavefront per token, per-token reductions by wave shuffles.
+// Restates the eval arithmetic of vector_quantize_pytorch.LFQ / FSQ (see oracle/thirdparty.py for
+// the algorithm statement; reference call sites magvit2_pytorch.py:1574, 1593, 1700, 1705).
+#include "common.h"
+
+#define CB_MAX 32
+
+struct QuantParams {
+    const void* x; const float* w_in; const float* b_in; const float* w_out; const float* b_out;
+    void* quantized; void* ids; float* prequant;
+    int64_t rows; int C, cb_dim, ncb;
+    float clamp, scale;
+    // FSQ constants (per codebook dim, length cb_dim)
+    const float* shift; const float* half_l; const float* offset; const float* half_w; const int32_t* basis;
+};
+
+// z[i] = b_in[i] + sum_c W_in[i][c] x[c]   (wave-reduced; every lane ends with all cbt sums)
+template <typename E>
+__device__ __forceinline__ void project_in(const QuantParams& p, int64_t row, int lane, int cbt, float* z) {
+    const int nch = p.C / E::kVec;
+#pragma unroll
+    for (int i = 0; i < CB_MAX; ++i) z[i] = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        float xv[8];
+        Chunk<E>::unpack(*(const i32x4*)((const char*)p.x + (row * p.C + (int64_t)ch * E::kVec) * E::kBytes), xv);
+#pragma unroll
+        for (int i = 0; i < CB_MAX; ++i) {
+            if (i < cbt) {
+                const float* w = p.w_in + (int64_t)i * p.C + ch * E::kVec;
+#pragma unroll
+                for (int k = 0; k < E::kVec; ++k) z[i] += xv[k] * w[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CB_MAX; ++i) if (i < cbt) z[i] = wave_sum(z[i]) + p.b_in[i];
+}
+
+// out[c] = b_out[c] + sum_i W_out[c][i] code[i]
+template <typename E>
+__device__ __forceinline__ void project_out(const float* w_out, const float* b_out, void* out, int64_t row, int C, int lane,
+                                            int cbt, const float* code) {
+    const int nch = C / E::kVec;
+    for (int ch = lane; ch < nch; ch += 64) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < E::kVec; ++k) {
+            const int c = ch * E::kVec + k;
+            float a = b_out[c];
+            const float* w = w_out + (int64_t)c * cbt;
+#pragma unroll
+            for (int i = 0; i < CB_MAX; ++i) if (i < cbt) a += w[i] * code[i];
+            o[k] = a;
+        }
+        *(i32x4*)((char*)out + (row * C + (int64_t)ch * E::kVec) * E::kBytes) = Chunk<E>::pack(o);
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void lfq_kernel(const QuantParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int cbt = p.cb_dim * p.ncb;
+    float z[CB_MAX], code[CB_MAX];
+    project_in<E>(p, row, lane, cbt, z);
+#pragma unroll
+    for (int i = 0; i < CB_MAX; ++i) {
+        code[i] = 0.f;
+        if (i < cbt) {
+            if (p.clamp > 0.f) z[i] = tanhf(z[i] / p.clamp) * p.clamp;
+            code[i] = z[i] > 0.f ? p.scale : -p.scale;
+        }
+    }
+    if (lane == 0) {
+        for (int cbk = 0; cbk < p.ncb; ++cbk) {
+            int64_t id = 0;
+#pragma unroll
+            for (int i = 0; i < CB_MAX; ++i) {
+                const int li = i - cbk * p.cb_dim;
+                if (li >= 0 && li < p.cb_dim && z[i] > 0.f) id |= (int64_t)1 << (p.cb_dim - 1 - li);
+            }
+            ((int64_t*)p.ids)[row * p.ncb + cbk] = id;
+        }
+        if (p.prequant) {
+#pragma unroll
+            for (int i = 0; i < CB_MAX; ++i) if (i < cbt) p.prequant[row * cbt + i] = z[i];
+        }
+    }
+    project_out<E>(p.w_out, p.b_out, p.quantized, row, p.C, lane, cbt, code);
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void fsq_kernel(const QuantParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int cbt = p.cb_dim * p.ncb;
+    float z[CB_MAX], code[CB_MAX], lvl[CB_MAX];
+    project_in<E>(p, row, lane, cbt, z);
+#pragma unroll
+    for (int i = 0; i < CB_MAX; ++i) {
+        code[i] = 0.f; lvl[i] = 0.f;
+        if (i < cbt) {
+            const int li = i % p.cb_dim;
+            const float bounded = tanhf(z[i] + p.shift[li]) * p.half_l[li] - p.offset[li];
+            z[i] = bounded;
+            const float r = rintf(bounded);                  // round half to even, as torch.round
+            code[i] = r / p.half_w[li];
+            lvl[i] = (code[i] * p.half_w[li] + p.half_w[li]) * (float)p.basis[li];
+        }
+    }
+    if (lane == 0) {
+        for (int cbk = 0; cbk < p.ncb; ++cbk) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < CB_MAX; ++i) {
+                const int li = i - cbk * p.cb_dim;
+                if (li >= 0 && li < p.cb_dim) s += lvl[i];
+            }
+            ((int32_t*)p.ids)[row * p.ncb + cbk] = (int32_t)s;
+        }
+        if (p.prequant) {
+#pragma unroll
+            for (int i = 0; i < CB_MAX; ++i) if (i < cbt) p.prequant[row * cbt + i] = z[i];
+        }
+    }
+    project_out<E>(p.w_out, p.b_out, p.quantized, row, p.C, lane, cbt, code);
+}
+
+struct CodesParams {
+    const void* ids; const float* w_out; const float* b_out; void* out;
+    int64_t rows; int C, cb_dim, ncb; float scale;
+    const int32_t* levels; const float* half_w; const int32_t* basis;
+};
+
+template <typename E, bool FSQ>
+__global__ __launch_bounds__(256) void codes_kernel(const CodesParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int cbt = p.cb_dim * p.ncb;
+    float code[CB_MAX];
+#pragma unroll
+    for (int i = 0; i < CB_MAX; ++i) {
+        code[i] = 0.f;
+        if (i < cbt) {
+            const int cbk = i / p.cb_dim, li = i % p.cb_dim;
+            if (FSQ) {
+                const int32_t id = ((const int32_t*)p.ids)[row * p.ncb + cbk];
+                const int lv = (id / p.basis[li]) % p.levels[li];
+                code[i] = ((float)lv - p.half_w[li]) / p.half_w[li];
+            } else {
+                const int64_t id = ((const int64_t*)p.ids)[row * p.ncb + cbk];
+                code[i] = ((id >> (p.cb_dim - 1 - li)) & 1) ? p.scale : -p.scale;
+            }
+        }
+    }
+    project_out<E>(p.w_out, p.b_out, p.out, row, p.C, lane, cbt, code);
+}
+
+static int check_q(int dtype, int64_t rows, int C, int cb_dim, int ncb) {
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (rows <= 0 || C % kvec != 0 || cb_dim <= 0 || ncb <= 0 || cb_dim * ncb > CB_MAX || cb_dim > 62) return MV2_EINVAL;
+    return MV2_OK;
+}
+
+extern "C" int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                       void* quantized, int64_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
+                       float clamp, float scale, void* stream) {
+    if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, clamp, scale,
+                  nullptr, nullptr, nullptr, nullptr, nullptr};
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((lfq_kernel<BF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((lfq_kernel<F32>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                       const float* shift, const float* half_l, const float* offset, const float* half_w, const int32_t* basis,
+                       void* quantized, int32_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
+                       void* stream) {
+    if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids || !shift || !half_l || !offset || !half_w || !basis) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, 0.f, 1.f,
+                  shift, half_l, offset, half_w, basis};
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((fsq_kernel<BF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((fsq_kernel<F32>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out, const float* b_out, void* out, int64_t rows,
+                             int C, int cb_dim, int num_codebooks, float scale, void* stream) {
+    if (!ids || !w_out || !b_out || !out) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    CodesParams p{ids, w_out, b_out, out, rows, C, cb_dim, num_codebooks, scale, nullptr, nullptr, nullptr};
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((codes_kernel<BF16, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((codes_kernel<F32, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_fsq_codes(int dtype, const int32_t* ids, const float* w_out, const float* b_out, const int32_t* levels,
+                             const float* half_w, const int32_t* basis, void* out, int64_t rows, int C, int cb_dim,
+                             int num_codebooks, void* stream) {
+    if (!ids || !w_out || !b_out || !out || !levels || !half_w || !basis) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    CodesParams p{ids, w_out, b_out, out, rows, C, cb_dim, num_codebooks, 1.f, levels, half_w, basis};
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((codes_kernel<BF16, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((codes_kernel<F32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

@@ -1,0 +1,124 @@
+"""
+TEST INFRASTRUCTURE — not product code.
+
+Loads the reference's own ``magvit2_pytorch.py`` + ``attend.py`` (read in place from
+/root/reference, never copied) so the *reference itself* can be executed on CPU in the
+authoring container.  It is used to (a) pin ``oracle/restate.py`` and (b) generate the
+golden fixtures under tests/golden/ (``oracle/make_golden.py``).  /root/reference does
+not exist on the GPU box: nothing that runs there may call ``load_reference``.
+
+The reference is not importable as a package here: its
+``__init__`` pulls trainer -> data -> cv2 / ema_pytorch / ..., and the model file imports
+beartype, torchvision, kornia, gateloop_transformer, vector_quantize_pytorch and
+taylor_series_linear_attention, none of which are installed.  We register ``sys.modules``
+stubs for the non-arithmetic ones, route the two arithmetic ones to
+``oracle/thirdparty.py`` (restatements, parity unpinned), create an empty package object
+that bypasses ``__init__.py`` and exec version.py / attend.py / magvit2_pytorch.py by path.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+import typing
+import warnings
+
+REFERENCE_ROOT = os.environ.get('MV2_REFERENCE_ROOT', '/root/reference')
+_PKG_DIR = os.path.join(REFERENCE_ROOT, 'magvit2_pytorch')
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(_PKG_DIR, 'magvit2_pytorch.py'))
+
+
+def _stub(name, **attrs):
+    if name in sys.modules:
+        mod = sys.modules[name]
+    else:
+        mod = types.ModuleType(name)
+        sys.modules[name] = mod
+    for k, v in attrs.items():
+        setattr(mod, k, v)
+    return mod
+
+
+def _beartype(obj=None, **_):
+    # usable bare (@beartype) on functions / classes -> identity
+    if obj is None:
+        return lambda o: o
+    return obj
+
+
+def _not_on_path(*_, **__):
+    raise RuntimeError('stubbed third-party symbol: not on the scoped hot path')
+
+
+def install_shims():
+    from . import thirdparty
+
+    _stub('beartype', beartype=_beartype)
+    _stub('beartype.typing', Tuple=typing.Tuple, List=typing.List, Optional=typing.Optional,
+          Union=typing.Union, Type=typing.Type, Literal=typing.Literal)
+
+    class _VGG16_Weights:
+        DEFAULT = None
+
+    tv_models = _stub('torchvision.models', VGG16_Weights=_VGG16_Weights, vgg16=_not_on_path)
+    _stub('torchvision', models=tv_models)
+
+    kf = _stub('kornia.filters', filter3d=_not_on_path)
+    _stub('kornia', filters=kf)
+
+    class _SimpleGateLoopLayer:   # only for 'gateloop_time' (out of scope)
+        def __init__(self, *a, **k):
+            _not_on_path()
+
+    _stub('gateloop_transformer', SimpleGateLoopLayer=_SimpleGateLoopLayer)
+    _stub('vector_quantize_pytorch', LFQ=thirdparty.LFQ, FSQ=thirdparty.FSQ)
+    _stub('taylor_series_linear_attention', TaylorSeriesLinearAttn=thirdparty.TaylorSeriesLinearAttn)
+
+
+_loaded = None
+
+
+def load_reference():
+    """Returns the reference's ``magvit2_pytorch.magvit2_pytorch`` module object."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not reference_available():
+        raise FileNotFoundError(f'{_PKG_DIR} not present (expected only in the authoring container)')
+    install_shims()
+
+    pkg = types.ModuleType('magvit2_pytorch')
+    pkg.__path__ = [_PKG_DIR]        # bypasses __init__.py
+    sys.modules['magvit2_pytorch'] = pkg
+
+    def _exec(sub):
+        spec = importlib.util.spec_from_file_location(f'magvit2_pytorch.{sub}', os.path.join(_PKG_DIR, f'{sub}.py'))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f'magvit2_pytorch.{sub}'] = mod
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            spec.loader.exec_module(mod)
+        setattr(pkg, sub, mod)
+        return mod
+
+    _exec('version')
+    _exec('attend')
+    _loaded = _exec('magvit2_pytorch')
+    return _loaded
+
+
+def make_reference_tokenizer(**kwargs):
+    """Reference ``VideoTokenizer`` (magvit2_pytorch.py:1045) in eval mode with VGG / GAN
+    construction switched off (perceptual_loss_weight=0 -> VGG never built, :1392)."""
+    ref = load_reference()
+    kwargs.setdefault('perceptual_loss_weight', 0.)
+    kwargs.setdefault('use_gan', False)
+    kwargs.setdefault('flash_attn', False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        tok = ref.VideoTokenizer(**kwargs)
+    return tok.eval()

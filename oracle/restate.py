@@ -1,0 +1,395 @@
+"""
+TEST INFRASTRUCTURE — not product code.  Only tests/, __graft_entry__.smoke() and
+bench.py's ``cpu_baseline`` leg may import this; the product path never does.
+
+A self-contained CPU restatement (plain torch, functional, fp32 or fp64) of the reference's
+VideoTokenizer eval hot path.  It needs nothing from /root/reference, so it travels to the
+GPU box as the checker and as the ``cpu_baseline`` ("port").  Each function cites the
+reference lines it follows (M = magvit2_pytorch/magvit2_pytorch.py, A = attend.py).
+
+Pinning: ``tests/test_oracle_vs_reference.py`` (runs only where /root/reference exists)
+executes the *reference's own code* (oracle/ref_loader.py) on the same weights/inputs and
+requires this restatement to agree (ids identical, tensors to fp32 round-off), and
+``tests/golden/`` holds outputs of the reference itself (oracle/make_golden.py) that this
+file is checked against on every box.  The LFQ / FSQ / Taylor-attention arithmetic is a
+reconstruction of un-vendored third-party packages: PARITY UNPINNED for those three pieces
+(see oracle/thirdparty.py), pinned for everything else.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- spec parsing
+def parse_layers(layers, init_dim, max_dim):
+    """Layer-spec grammar of M:1138-1318, reduced to the scoped (un-conditioned) layer types.
+    Returns a list of dicts {kind, dim, dim_out, n} in encoder order."""
+    out = []
+    dim = init_dim
+    for ld in layers:
+        kind, *params = ld if isinstance(ld, tuple) else (ld,)
+        dim_out = dim
+        n = 1
+        if kind == 'residual':
+            pass
+        elif kind == 'consecutive_residual':
+            n, = params
+        elif kind in ('compress_space', 'compress_time'):
+            dim_out = params[0] if len(params) > 0 and params[0] is not None else dim * 2
+            dim_out = min(dim_out, max_dim)
+        elif kind in ('attend_space', 'linear_attend_space', 'attend_time'):
+            pass
+        else:
+            raise ValueError(f'unknown / unscoped layer type {kind}')
+        out.append(dict(kind=kind, dim=dim, dim_out=dim_out, n=n))
+        dim = dim_out
+    return out
+
+
+# ----------------------------------------------------------------------------- blocks
+def causal_conv3d(x, w, b, stride=1):
+    """M:892-928: front-pad time by (kt-1) + (1-stride), same-pad H/W, constant zeros."""
+    kt, kh, kw = w.shape[2:]
+    tp = (kt - 1) + (1 - stride)
+    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, tp, 0))
+    return F.conv3d(x, w, b, stride=(stride, 1, 1))
+
+
+def squeeze_excite(x, p, pre):
+    """M:221-240 on a 5-D tensor: per (b, t) frame softmax-pooled context -> 2-layer gate."""
+    B, C, T, H, W = x.shape
+    fr = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H * W)
+    wk = p[pre + 'to_k.weight'].reshape(C)
+    logits = torch.einsum('c,ncp->np', wk, fr) + p[pre + 'to_k.bias']
+    attn = logits.softmax(dim=-1)
+    pooled = torch.einsum('np,ncp->nc', attn, fr)
+    w1 = p[pre + 'net.0.weight'].flatten(1)
+    w2 = p[pre + 'net.2.weight'].flatten(1)
+    h = F.leaky_relu(pooled @ w1.t() + p[pre + 'net.0.bias'], 0.1)
+    g = torch.sigmoid(h @ w2.t() + p[pre + 'net.2.bias'])
+    g = g.reshape(B, T, C).permute(0, 2, 1)[..., None, None]
+    return x * g
+
+
+def residual_unit(x, p, pre):
+    """M:930-944: x + SE(ELU(conv1x1x1(ELU(causal_conv3d_k(x)))))."""
+    y = F.elu(causal_conv3d(x, p[pre + 'fn.0.conv.weight'], p[pre + 'fn.0.conv.bias']))
+    y = F.elu(F.conv3d(y, p[pre + 'fn.2.weight'], p[pre + 'fn.2.bias']))
+    y = squeeze_excite(y, p, pre + 'fn.4.')
+    return y + x
+
+
+def spatial_down(x, p, pre):
+    """M:770-780: per-frame Conv2d k3 s2 p1."""
+    B, C, T, H, W = x.shape
+    fr = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    w = p[pre + 'conv.weight']
+    k = w.shape[-1]
+    o = F.conv2d(fr, w, p[pre + 'conv.bias'], stride=2, padding=k // 2)
+    return o.reshape(B, T, *o.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def time_down(x, p, pre):
+    """M:796-807: per-pixel causal Conv1d k3 s2, left pad k-1."""
+    B, C, T, H, W = x.shape
+    seq = x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, T)
+    w = p[pre + 'conv.weight']
+    seq = F.pad(seq, (w.shape[-1] - 1, 0))
+    o = F.conv1d(seq, w, p[pre + 'conv.bias'], stride=2)
+    return o.reshape(B, H, W, o.shape[1], o.shape[2]).permute(0, 3, 4, 1, 2)
+
+
+def spatial_up(x, p, pre):
+    """M:838-846: Conv2d 1x1 C -> 4C', SiLU, 'b (c p1 p2) h w -> b c (h p1) (w p2)'."""
+    B, C, T, H, W = x.shape
+    fr = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    o = F.silu(F.conv2d(fr, p[pre + 'net.0.weight'], p[pre + 'net.0.bias']))
+    co = o.shape[1] // 4
+    o = o.reshape(B * T, co, 2, 2, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B * T, co, H * 2, W * 2)
+    return o.reshape(B, T, co, H * 2, W * 2).permute(0, 2, 1, 3, 4)
+
+
+def time_up(x, p, pre):
+    """M:875-883: Conv1d k1 C -> 2C', SiLU, 'b (c p) t -> b c (t p)'."""
+    B, C, T, H, W = x.shape
+    seq = x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, T)
+    o = F.silu(F.conv1d(seq, p[pre + 'net.0.weight'], p[pre + 'net.0.bias']))
+    co = o.shape[1] // 2
+    o = o.reshape(B * H * W, co, 2, T).permute(0, 1, 3, 2).reshape(B * H * W, co, T * 2)
+    return o.reshape(B, H, W, co, T * 2).permute(0, 3, 4, 1, 2)
+
+
+def rmsnorm_last(x, gamma):
+    """M:275-276 (channel-last): F.normalize(x, dim=-1) * sqrt(dim) * gamma."""
+    return F.normalize(x, dim=-1) * (x.shape[-1] ** 0.5) * gamma
+
+
+def attend(q, k, v, causal):
+    """A:186-243 (einsum path): softmax(q k^T d^-1/2 [+ right-aligned causal mask]) v."""
+    n, j = q.shape[-2], k.shape[-2]
+    dots = torch.einsum('bhid,bhjd->bhij', q, k) * (q.shape[-1] ** -0.5)
+    if causal and n > 1:
+        mask = torch.ones((n, j), dtype=torch.bool).triu(j - n + 1)            # A:46-47
+        dots = dots.masked_fill(mask, -torch.finfo(dots.dtype).max)
+    return torch.einsum('bhij,bhjd->bhid', dots.softmax(dim=-1), v)
+
+
+def attention_tokens(tok, p, pre, heads, causal):
+    """M:371-388 on tokens (b', n, C): norm -> qkv -> prepend mem_kv -> attend -> out."""
+    b, n, C = tok.shape
+    xn = rmsnorm_last(tok, p[pre + 'norm.gamma'])
+    qkv = xn @ p[pre + 'to_qkv.0.weight'].t()
+    d = qkv.shape[-1] // (3 * heads)
+    qkv = qkv.reshape(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)                 # qkv b h n d
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    mk, mv = p[pre + 'mem_kv'][0], p[pre + 'mem_kv'][1]
+    k = torch.cat((mk.expand(b, -1, -1, -1), k), dim=-2)
+    v = torch.cat((mv.expand(b, -1, -1, -1), v), dim=-2)
+    o = attend(q, k, v, causal)
+    o = o.transpose(1, 2).reshape(b, n, heads * d)
+    return o @ p[pre + 'to_out.1.weight'].t()
+
+
+def space_attention(x, p, pre, heads):
+    """M:444-454: tokens = H*W per (b, t) frame."""
+    B, C, T, H, W = x.shape
+    tok = x.permute(0, 2, 3, 4, 1).reshape(B * T, H * W, C)
+    o = attention_tokens(tok, p, pre, heads, causal=False)
+    return o.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+
+
+def time_attention(x, p, pre, heads):
+    """M:456-464: tokens = T per (b, h, w) pixel, causal."""
+    B, C, T, H, W = x.shape
+    tok = x.permute(0, 3, 4, 2, 1).reshape(B * H * W, T, C)
+    o = attention_tokens(tok, p, pre, heads, causal=True)
+    return o.reshape(B, H, W, T, C).permute(0, 4, 3, 1, 2)
+
+
+def taylor_feature(x):
+    x0 = x.new_ones(x.shape[:-1] + (1,))
+    x2 = (x.unsqueeze(-1) * x.unsqueeze(-2)).flatten(-2) * (0.5 ** 0.5)
+    return torch.cat((x0, x, x2), dim=-1)
+
+
+def linear_space_attention(x, p, pre, heads, dim_head):
+    """M:432-442 -> M:421-430 -> third-party TaylorSeriesLinearAttn (reconstruction)."""
+    B, C, T, H, W = x.shape
+    tok = x.permute(0, 2, 3, 4, 1).reshape(B * T, H * W, C)
+    xn = rmsnorm_last(tok, p[pre + 'norm.gamma'])
+    b, n, _ = xn.shape
+    q = (xn @ p[pre + 'attn.to_q.0.weight'].t()).reshape(b, n, heads, dim_head).transpose(1, 2)
+    kv = (xn @ p[pre + 'attn.to_kv.0.weight'].t()).reshape(b, n, 2, heads, dim_head).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    q = taylor_feature(q * dim_head ** -0.5)
+    k = taylor_feature(k)
+    kvs = torch.einsum('bhnd,bhne->bhde', k, v)
+    qk_inv = 1. / torch.einsum('bhnd,bhd->bhn', q, k.sum(dim=-2)).clamp(min=1e-5)
+    o = torch.einsum('bhnd,bhde,bhn->bhne', q, kvs, qk_inv)
+    o = o.transpose(1, 2).reshape(b, n, heads * dim_head) @ p[pre + 'attn.to_out.0.weight'].t()
+    return o.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+
+
+def feed_forward(x, p, pre):
+    """M:499-508 / GEGLU M:466-469: channel-first RMSNorm -> 1x1x1 -> gelu(gate) * x -> 1x1x1."""
+    C = x.shape[1]
+    xn = F.normalize(x, dim=1) * (C ** 0.5) * p[pre + 'norm.gamma']
+    h = F.conv3d(xn, p[pre + 'net.0.weight'], p[pre + 'net.0.bias'])
+    a, gate = h.chunk(2, dim=1)
+    h = F.gelu(gate) * a
+    return F.conv3d(h, p[pre + 'net.2.weight'], p[pre + 'net.2.bias'])
+
+
+def token_shift(x):
+    """M:250-253: second half of the channels delayed by one frame, zero at t = 0."""
+    a, s = x.chunk(2, dim=1)
+    s = F.pad(s, (0, 0, 0, 0, 1, -1))
+    return torch.cat((a, s), dim=1)
+
+
+# ----------------------------------------------------------------------------- quantizers
+def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1.):
+    """third-party LFQ.forward eval path (reconstruction; see oracle/thirdparty.py)."""
+    B, C = x.shape[:2]
+    sp = x.shape[2:]
+    tok = x.reshape(B, C, -1).transpose(1, 2)
+    z = tok @ p['quantizers.project_in.weight'].t() + p['quantizers.project_in.bias']
+    if clamp is not None:
+        z = (z / clamp).tanh() * clamp
+    z = z.reshape(B, -1, num_codebooks, codebook_dim).float()
+    pos = z > 0
+    mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
+    ids = (pos.int() * mask).sum(dim=-1)                                       # int64
+    q = torch.where(pos, torch.full_like(z, scale), torch.full_like(z, -scale)).to(x.dtype)
+    q = q.reshape(B, -1, num_codebooks * codebook_dim)
+    out = q @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    out = out.transpose(1, 2).reshape(B, C, *sp)
+    ids = ids.reshape(B, *sp, num_codebooks)
+    if num_codebooks == 1:
+        ids = ids.squeeze(-1)
+    return out, ids, z.reshape(B, *sp, num_codebooks * codebook_dim)
+
+
+def lfq_indices_to_codes(ids, p, codebook_dim, num_codebooks=1, scale=1.):
+    dtype = p['quantizers.project_out.weight'].dtype
+    if num_codebooks == 1:
+        ids = ids.unsqueeze(-1)
+    mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
+    bits = ((ids[..., None].int() & mask) != 0).to(dtype)
+    codes = (bits * scale * 2 - scale).flatten(-2)
+    out = codes @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    return out.movedim(-1, 1)
+
+
+def _fsq_consts(levels, dtype):
+    L = torch.tensor(levels, dtype=torch.int32)
+    basis = torch.cumprod(torch.tensor([1] + list(levels[:-1])), dim=0, dtype=torch.int32)
+    half_l = (L - 1) * (1 + 1e-3) / 2
+    offset = torch.where(L % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    return L, basis, half_l, offset, shift, L // 2
+
+
+def fsq_quantize(x, p, levels):
+    """third-party FSQ.forward (reconstruction)."""
+    B, C = x.shape[:2]
+    sp = x.shape[2:]
+    tok = x.reshape(B, C, -1).transpose(1, 2)
+    z = tok @ p['quantizers.project_in.weight'].t() + p['quantizers.project_in.bias']
+    L, basis, half_l, offset, shift, hw = _fsq_consts(levels, z.dtype)
+    bounded = (z + shift).tanh() * half_l - offset
+    codes = bounded.round() / hw
+    ids = ((codes * hw + hw) * basis).sum(dim=-1).to(torch.int32)
+    out = codes.to(x.dtype) @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    return out.transpose(1, 2).reshape(B, C, *sp), ids.reshape(B, *sp), bounded.reshape(B, *sp, len(levels))
+
+
+def fsq_indices_to_codes(ids, p, levels):
+    L, basis, half_l, offset, shift, hw = _fsq_consts(levels, torch.float32)
+    lv = (ids.unsqueeze(-1) // basis) % L
+    codes = ((lv - hw) / hw).to(p['quantizers.project_out.weight'].dtype)
+    out = codes @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    return out.movedim(-1, 1)
+
+
+# ----------------------------------------------------------------------------- the tokenizer
+class OracleTokenizer:
+    """Functional restatement of VideoTokenizer eval paths (M:1522-1720) over a plain
+    ``state_dict`` with the reference's key names."""
+
+    def __init__(self, state_dict, *, image_size, layers, codebook_size=None, init_dim=64, max_dim=float('inf'),
+                 channels=3, num_codebooks=1, use_fsq=False, fsq_levels=None, attn_dim_head=32, attn_heads=8,
+                 linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10.,
+                 dtype=torch.float32, **_ignored):
+        self.p = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone())
+                  for k, v in state_dict.items() if not k.startswith('discr.')}
+        self.dtype = dtype
+        self.image_size = image_size
+        self.channels = channels
+        self.stages = parse_layers(layers, init_dim, max_dim)
+        self.attn_heads = attn_heads
+        self.lin_heads, self.lin_dim_head = linear_attn_heads, linear_attn_dim_head
+        self.use_fsq = use_fsq
+        self.fsq_levels = list(fsq_levels) if fsq_levels is not None else None
+        self.num_codebooks = num_codebooks
+        self.codebook_dim = int(math.log2(codebook_size)) if codebook_size is not None else None
+        self.clamp = lfq_soft_clamp_input_value
+        self.time_downsample_factor = 2 ** sum(s['kind'] == 'compress_time' for s in self.stages)
+        self.time_padding = self.time_downsample_factor - 1
+        self.fmap_size = image_size // (2 ** sum(s['kind'] == 'compress_space' for s in self.stages))
+        self.taps = None            # optional dict name -> tensor for layer-wise debugging
+
+    def _tap(self, name, x):
+        if self.taps is not None:
+            self.taps[name] = x
+        return x
+
+    # stage dispatch, shared by encoder (enc=True) and decoder
+    def _stage(self, x, st, pre, enc):
+        p, kind = self.p, st['kind']
+        if kind == 'residual':
+            return residual_unit(x, p, pre + '.')
+        if kind == 'consecutive_residual':
+            for j in range(st['n']):
+                x = residual_unit(x, p, f'{pre}.{j}.')
+            return x
+        if kind == 'compress_space':
+            return spatial_down(x, p, pre + '.') if enc else spatial_up(x, p, pre + '.')
+        if kind == 'compress_time':
+            return time_down(x, p, pre + '.') if enc else time_up(x, p, pre + '.')
+        if kind == 'attend_space':
+            x = space_attention(x, p, pre + '.0.fn.', self.attn_heads) + x
+            return feed_forward(x, p, pre + '.1.fn.') + x
+        if kind == 'linear_attend_space':
+            x = linear_space_attention(x, p, pre + '.0.fn.', self.lin_heads, self.lin_dim_head) + x
+            return feed_forward(x, p, pre + '.1.fn.') + x
+        if kind == 'attend_time':
+            x = time_attention(token_shift(x), p, pre + '.0.fn.fn.', self.attn_heads) + x
+            return feed_forward(token_shift(x), p, pre + '.1.fn.fn.') + x
+        raise ValueError(kind)
+
+    def encode(self, video):
+        """M:1522-1576 (video_contains_first_frame=True, no cond, no separate first frame).
+        NB the trailing LayerNorm of encoder_layers is never executed (zip truncation, M:1565)."""
+        x = video.to(self.dtype)
+        x = F.pad(x, (0, 0, 0, 0, self.time_padding, 0))                        # M:1537
+        x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
+        for i, st in enumerate(self.stages):
+            x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True))
+        return x
+
+    def quantize(self, x):
+        if self.use_fsq:
+            q, ids, pre = fsq_quantize(x, self.p, self.fsq_levels)
+        else:
+            q, ids, pre = lfq_quantize(x, self.p, self.codebook_dim, self.num_codebooks, self.clamp)
+        self._tap('prequant', pre)
+        return self._tap('quantized', q), ids
+
+    def indices_to_codes(self, ids):
+        if self.use_fsq:
+            return fsq_indices_to_codes(ids, self.p, self.fsq_levels)
+        return lfq_indices_to_codes(ids, self.p, self.codebook_dim, self.num_codebooks)
+
+    def decode(self, q):
+        """M:1597-1649."""
+        x = q
+        n = len(self.stages)
+        for j, st in enumerate(reversed(self.stages)):
+            x = self._tap(f'dec{j}', self._stage(x, st, f'decoder_layers.{j}', False))
+        x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
+        return x[:, :, self.time_padding:]                                       # M:1646-1647
+
+    def decode_from_code_indices(self, codes):
+        """M:1578-1595."""
+        assert codes.dtype in (torch.long, torch.int32)
+        if codes.ndim == 2:
+            f2 = self.fmap_size ** 2
+            assert codes.shape[-1] % f2 == 0
+            codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
+        return self.decode(self.indices_to_codes(codes))
+
+    def tokenize(self, video):
+        return self.forward(video, return_codes=True)
+
+    def forward(self, video, return_codes=False, return_recon=False):
+        """M:1656-1720 eval branches."""
+        assert video.ndim in (4, 5)
+        assert video.shape[-2:] == (self.image_size, self.image_size)
+        if video.ndim == 4:
+            video = video.unsqueeze(2)
+        assert (video.shape[2] - 1) % self.time_downsample_factor == 0
+        with torch.no_grad():
+            x = self.encode(video)
+            q, ids = self.quantize(x)
+            if return_codes and not return_recon:
+                return ids
+            recon = self.decode(q)
+        if return_codes:
+            return ids, recon
+        return recon
+
+    __call__ = forward
