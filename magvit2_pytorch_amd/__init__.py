@@ -1,0 +1,6 @@
+"""MI355X-native VideoTokenizer hot path (encode -> quantize -> decode) behind the
+magvit2_pytorch.VideoTokenizer API.  Kernels: libmv2_hip.so (include/mv2.h)."""
+from .tokenizer import VideoTokenizer, __version__
+from .spec import README_LAYERS
+
+__all__ = ['VideoTokenizer', 'README_LAYERS', '__version__']

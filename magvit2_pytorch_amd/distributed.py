@@ -1,0 +1,98 @@
+"""
+Batch sharding for the tokenizer hot path: one process per GPU, clips are independent units.
+
+Every op on the path is per-sample (no BatchNorm; SqueezeExcite / softmax / attention reductions stay
+inside a clip; the eval quantizer has no cross-sample state — SURVEY.md §8e), so the data path needs
+NO collective: each rank encodes / decodes its own clips with replicated weights.  The only exchange
+is optional result gathering off the critical path — code ids (10 KB per 17-frame clip) via one
+all_gather, and a few fp32 metric sums via one all_reduce — over RCCL/xGMI (``backend='nccl'`` is RCCL
+on ROCm); both are latency-bound single small messages, so no bucketing is needed.  The reference has
+no equivalent (its only parallelism is accelerate/DDP training, trainer.py:44-46, 97-102).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, rank: int, world_size: int):
+    """contiguous, balanced split of n clips: the first n % world ranks take one extra."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(video: torch.Tensor):
+    rank, ws = world()
+    lo, hi = shard_bounds(video.shape[0], rank, ws)
+    return video[lo:hi]
+
+
+def gather_codes(local_codes: torch.Tensor, total: int) -> torch.Tensor:
+    """all_gather of the per-rank code ids into the global (total, ...) tensor (ragged-safe)."""
+    rank, ws = world()
+    if ws == 1:
+        return local_codes
+    counts = [shard_bounds(total, r, ws)[1] - shard_bounds(total, r, ws)[0] for r in range(ws)]
+    mx = max(counts)
+    pad = local_codes.new_zeros((mx,) + tuple(local_codes.shape[1:]))
+    pad[: local_codes.shape[0]] = local_codes
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def reduce_metrics(sums: Dict[str, float], device=None) -> Dict[str, float]:
+    """one all_reduce(SUM) of a few fp32 scalars (e.g. squared-error sum, element count)."""
+    rank, ws = world()
+    if ws == 1:
+        return dict(sums)
+    keys = sorted(sums)
+    t = torch.tensor([float(sums[k]) for k in keys], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
+@torch.no_grad()
+def tokenize_sharded(tokenizer, video: torch.Tensor, gather: bool = True):
+    """each rank tokenizes its shard of the global batch; optionally gathers all ids everywhere."""
+    local = shard_batch(video)
+    codes = tokenizer.tokenize(local.to(tokenizer.device) if tokenizer.device.type == 'cuda' else local)
+    return gather_codes(codes, video.shape[0]) if gather else codes
+
+
+@torch.no_grad()
+def reconstruction_metrics_sharded(tokenizer, video: torch.Tensor) -> Dict[str, float]:
+    """global MSE / PSNR of forward(video) over a sharded batch: local sums + one tiny all_reduce."""
+    local = shard_batch(video)
+    dev_in = local.to(tokenizer.device) if tokenizer.device.type == 'cuda' else local
+    recon = tokenizer(dev_in, return_recon=True)
+    ref = dev_in.unsqueeze(2) if dev_in.ndim == 4 else dev_in
+    se = (recon.float() - ref.float()).pow(2).sum().item()
+    tot = reduce_metrics(dict(se=se, n=float(ref.numel())), device=recon.device if recon.is_cuda else None)
+    mse = tot['se'] / max(tot['n'], 1.0)
+    return dict(mse=mse, psnr=float('inf') if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item())

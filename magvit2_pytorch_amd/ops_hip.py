@@ -1,0 +1,212 @@
+"""
+ctypes binding of libmv2_hip.so (include/mv2.h) — the only compute backend of the product path.
+
+There is deliberately NO CPU fallback: if the library is missing, cannot be loaded, or no HIP
+device is present, constructing ``HipOps`` raises.  Every method returns a *step*: a closure
+``step(stream_ptr)`` that launches the kernel(s) on the given HIP stream with arguments frozen at
+plan-build time (device pointers of statically allocated torch tensors), so a forward pass is a
+flat list of C calls that can be captured into a HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import pack as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmv2_hip.so')
+
+
+class Mv2Error(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'dtype', 'B', 'Ti', 'Hi', 'Wi', 'Ci', 'To', 'Ho', 'Wo', 'co', 'co_pad', 'st', 'sh', 'sw', 'pt', 'ph', 'pw',
+        'kt', 'kh', 'kw', 'nsteps', 'seg_bytes', 'check_bounds', 'act', 'store', 'rt', 'rh', 'rw', 'crop_t', 'out_c',
+        'splitk')]
+
+
+_SIGS = {
+    'mv2_abi_version': (C.c_int, []),
+    'mv2_device_cus': (C.c_int, []),
+    'mv2_conv_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_video_to_ndhwc': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
+    'mv2_rms_rowscale': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_se_pool': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_se_gate': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+    'mv2_se_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_attention': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_int64, C.c_int64, C.c_void_p]),
+    'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_lfq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'mv2_fsq': (C.c_int, [C.c_int] + [C.c_void_p] * 13 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_fsq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_event_create': (C.c_void_p, []),
+    'mv2_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mv2_event_sync': (C.c_int, [C.c_void_p]),
+    'mv2_event_elapsed_ms': (C.c_float, [C.c_void_p, C.c_void_p]),
+    'mv2_event_destroy': (None, [C.c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load_library():
+    """Loads libmv2_hip.so and declares every prototype of include/mv2.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Mv2Error(f'{LIB_PATH} not built: run `python -m magvit2_pytorch_amd.build` (hipcc, gfx950). '
+                       'There is no CPU fallback for the product path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Mv2Error(f'{what} failed with code {rc}')
+
+
+def _mk(fn, args, what, keep, outs):
+    def step(stream, _fn=fn, _args=args, _what=what, _keep=keep):
+        rc = _fn(*_args, stream)
+        if rc != 0:
+            raise Mv2Error(f'{_what} failed with code {rc}')
+    step.outs = [o for o in outs if o is not None]      # tensors this launch writes (lockstep parity runner)
+    step.what = what
+    return step
+
+
+class HipOps:
+    """Kernel launcher over the C ABI.  All tensors must live on ``device`` (a HIP device)."""
+    name = 'hip'
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise Mv2Error('no HIP device visible: the product path has no CPU fallback')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        with torch.cuda.device(self.device):
+            cus = self.lib.mv2_device_cus()
+        if cus <= 0:
+            raise Mv2Error(f'mv2_device_cus() = {cus}')
+        self.cus = cus
+
+    # ---- allocation (plumbing only)
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t):
+        return t.to(self.device)
+
+    # ---- steps
+    def conv_workspace_bytes(self, d: dict) -> int:
+        desc = ConvDesc(**d)
+        with torch.cuda.device(self.device):
+            return int(self.lib.mv2_conv_workspace_bytes(C.byref(desc)))
+
+    def conv(self, d: dict, x, in_bytes, wp, segs, bias, rowscale, residual, out, ws):
+        desc = ConvDesc(**d)
+        fn = self.lib.mv2_conv
+        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp), _ptr(segs), _ptr(bias), _ptr(rowscale), _ptr(residual),
+                _ptr(out), _ptr(ws), 0 if ws is None else ws.numel() * ws.element_size())
+        keep = (desc, x, wp, segs, bias, rowscale, residual, out, ws)
+
+        return _mk(fn, args, 'mv2_conv', keep, [out, ws])
+
+    def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
+        fn, args = self.lib.mv2_video_to_ndhwc, (dt, _ptr(video), _ptr(out), B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems)
+        keep = (video, out)
+        return _mk(fn, args, 'mv2_video_to_ndhwc', keep, [out])
+
+    def rms_rowscale(self, dt, x, rs, rows, Cc, shift_hw, T):
+        fn, args = self.lib.mv2_rms_rowscale, (dt, _ptr(x), _ptr(rs), rows, Cc, shift_hw, T)
+        keep = (x, rs)
+        return _mk(fn, args, 'mv2_rms_rowscale', keep, [rs])
+
+    def se_pool(self, dt, y, wk, bk, part, frames, Pn, Cc, nchunk):
+        fn, args = self.lib.mv2_se_pool, (dt, _ptr(y), _ptr(wk), float(bk), _ptr(part), frames, Pn, Cc, nchunk)
+        keep = (y, wk, part)
+        return _mk(fn, args, 'mv2_se_pool', keep, [part])
+
+    def se_gate(self, part, w1, b1, w2, b2, gate, frames, Cc, hidden, nchunk):
+        fn, args = self.lib.mv2_se_gate, (_ptr(part), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gate), frames, Cc, hidden, nchunk)
+        keep = (part, w1, b1, w2, b2, gate)
+        return _mk(fn, args, 'mv2_se_gate', keep, [gate])
+
+    def se_apply(self, dt, y, gate, residual, out, frames, Pn, Cc):
+        fn, args = self.lib.mv2_se_apply, (dt, _ptr(y), _ptr(gate), _ptr(residual), _ptr(out), frames, Pn, Cc)
+        keep = (y, gate, residual, out)
+        return _mk(fn, args, 'mv2_se_apply', keep, [out])
+
+    def attention(self, dt, qkv, mem_kv, out, nseq, n, heads, dim_head, n_mem, causal, seq_inner, seq_outer_stride, tok_stride):
+        fn = self.lib.mv2_attention
+        args = (dt, _ptr(qkv), _ptr(mem_kv), _ptr(out), nseq, n, heads, dim_head, n_mem, int(causal), seq_inner,
+                seq_outer_stride, tok_stride)
+        keep = (qkv, mem_kv, out)
+        return _mk(fn, args, 'mv2_attention', keep, [out])
+
+    def taylor_kv(self, dt, kv, part, frames, n, heads, nchunk):
+        fn, args = self.lib.mv2_taylor_kv, (dt, _ptr(kv), _ptr(part), frames, n, heads, nchunk)
+        keep = (kv, part)
+        return _mk(fn, args, 'mv2_taylor_kv', keep, [part])
+
+    def taylor_apply(self, dt, q, part, out, kvsum, frames, n, heads, nchunk):
+        fn, args = self.lib.mv2_taylor_apply, (dt, _ptr(q), _ptr(part), _ptr(out), _ptr(kvsum), frames, n, heads, nchunk)
+        keep = (q, part, out, kvsum)
+        return _mk(fn, args, 'mv2_taylor_apply', keep, [out, kvsum])
+
+    def lfq(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
+        fn = self.lib.mv2_lfq
+        args = (dt, _ptr(x), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out), _ptr(quantized), _ptr(ids), _ptr(prequant),
+                rows, Cc, cb_dim, ncb, float(clamp), float(scale))
+        keep = (x, w_in, b_in, w_out, b_out, quantized, ids, prequant)
+        return _mk(fn, args, 'mv2_lfq', keep, [quantized, ids, prequant])
+
+    def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):
+        fn, args = self.lib.mv2_lfq_codes, (dt, _ptr(ids), _ptr(w_out), _ptr(b_out), _ptr(out), rows, Cc, cb_dim, ncb, float(scale))
+        keep = (ids, w_out, b_out, out)
+        return _mk(fn, args, 'mv2_lfq_codes', keep, [out])
+
+    def fsq(self, dt, x, w_in, b_in, w_out, b_out, consts, quantized, ids, prequant, rows, Cc, cb_dim, ncb):
+        fn = self.lib.mv2_fsq
+        args = (dt, _ptr(x), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out), _ptr(consts['shift']), _ptr(consts['half_l']),
+                _ptr(consts['offset']), _ptr(consts['half_w']), _ptr(consts['basis']), _ptr(quantized), _ptr(ids),
+                _ptr(prequant), rows, Cc, cb_dim, ncb)
+        keep = (x, w_in, b_in, w_out, b_out, consts, quantized, ids, prequant)
+        return _mk(fn, args, 'mv2_fsq', keep, [quantized, ids, prequant])
+
+    def fsq_codes(self, dt, ids, w_out, b_out, consts, out, rows, Cc, cb_dim, ncb):
+        fn = self.lib.mv2_fsq_codes
+        args = (dt, _ptr(ids), _ptr(w_out), _ptr(b_out), _ptr(consts['levels']), _ptr(consts['half_w']), _ptr(consts['basis']),
+                _ptr(out), rows, Cc, cb_dim, ncb)
+        keep = (ids, w_out, b_out, consts, out)
+        return _mk(fn, args, 'mv2_fsq_codes', keep, [out])
+
+    # ---- stream / timing plumbing
+    def current_stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)

@@ -1,0 +1,390 @@
+"""
+Execution plans: the layer-spec tuple lowered to a flat list of kernel launches.
+
+``PackedModel`` holds the dtype-specific packed weights of one state_dict (built once per dtype /
+device).  ``Plan`` lowers encode / quantize / decode for a fixed input geometry (B, T, H, W) into
+*steps* — closures ``step(stream)`` produced by an ops backend (``ops_hip.HipOps`` in the product;
+tests inject the CPU emulation of the kernel semantics from ``oracle/ndhwc_ops.py`` to validate this
+host logic where no GPU exists).  All activations are NDHWC; buffers are allocated once at plan
+build (static addresses -> HIP-graph capturable) and recycled through a size-keyed free list so the
+working set stays inside the 256 MiB Infinity Cache where it can.
+
+Reference control flow being lowered: VideoTokenizer.encode magvit2_pytorch.py:1522-1576,
+decode :1597-1649, decode_from_code_indices :1578-1595, forward (eval branches) :1656-1720.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import pack as P
+from .spec import Stage, parse_layers, se_hidden, ff_inner
+
+
+class PackedModel:
+    def __init__(self, cfg: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype, ops):
+        self.cfg, self.dtype, self.ops = cfg, dtype, ops
+        self.dt = P.dtype_code(dtype)
+        self.stages: List[Stage] = parse_layers(cfg['layers'], cfg['init_dim'], cfg['max_dim'])
+        self.c_in_pad = int(os.environ.get('MV2_CONVIN_CPAD', '8' if dtype == torch.bfloat16 else '4'))
+        f = lambda k: sd[k].detach().float().cpu()
+        dev = ops.to_device
+        self.convs: Dict[str, P.PackedConv] = {}
+        self.f32: Dict[str, torch.Tensor] = {}
+        self.hidden_pad: Dict[str, int] = {}
+
+        def put(name, pc):
+            self.convs[name] = pc.to(ops.device)
+
+        put('conv_in', P.pack_conv_in(f('conv_in.conv.weight'), f('conv_in.conv.bias'), dtype, self.c_in_pad))
+        put('conv_out', P.pack_conv3d(f('conv_out.conv.weight'), f('conv_out.conv.bias'), dtype))
+
+        def residual_unit(pre):
+            put(pre + '.k3', P.pack_conv3d(f(pre + '.fn.0.conv.weight'), f(pre + '.fn.0.conv.bias'), dtype))
+            put(pre + '.k1', P.pack_pointwise(f(pre + '.fn.2.weight').flatten(1), f(pre + '.fn.2.bias'), dtype))
+            c = sd[pre + '.fn.2.weight'].shape[0]
+            self.f32[pre + '.se.wk'] = dev(f(pre + '.fn.4.to_k.weight').reshape(c).contiguous())
+            self.f32[pre + '.se.bk'] = f(pre + '.fn.4.to_k.bias').reshape(())          # host scalar
+            self.f32[pre + '.se.w1'] = dev(f(pre + '.fn.4.net.0.weight').flatten(1).contiguous())
+            self.f32[pre + '.se.b1'] = dev(f(pre + '.fn.4.net.0.bias'))
+            self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).contiguous())
+            self.f32[pre + '.se.b2'] = dev(f(pre + '.fn.4.net.2.bias'))
+
+        def feed_forward(pre, dim, token_shift):
+            g = f(pre + '.norm.gamma').reshape(dim) * (dim ** 0.5)
+            pc, hp = P.pack_geglu_in(f(pre + '.net.0.weight').flatten(1), f(pre + '.net.0.bias'), dtype, in_scale=g,
+                                     token_shift=token_shift)
+            put(pre + '.ff1', pc)
+            self.hidden_pad[pre] = hp
+            put(pre + '.ff2', P.pack_pointwise(f(pre + '.net.2.weight').flatten(1), f(pre + '.net.2.bias'), dtype, k_pad=hp))
+
+        def attention(pre, dim, token_shift):
+            g = f(pre + '.norm.gamma') * (dim ** 0.5)
+            packer = P.pack_token_shift if token_shift else P.pack_pointwise
+            put(pre + '.qkv', packer(f(pre + '.to_qkv.0.weight'), None, dtype, in_scale=g))
+            put(pre + '.out', P.pack_pointwise(f(pre + '.to_out.1.weight'), None, dtype))
+            self.f32[pre + '.mem_kv'] = dev(f(pre + '.mem_kv').contiguous())
+
+        def linear_attention(pre, dim):
+            g = f(pre + '.norm.gamma') * (dim ** 0.5)
+            put(pre + '.q', P.pack_pointwise(f(pre + '.attn.to_q.0.weight'), None, dtype, in_scale=g))
+            put(pre + '.kv', P.pack_pointwise(f(pre + '.attn.to_kv.0.weight'), None, dtype, in_scale=g))
+            put(pre + '.out', P.pack_pointwise(f(pre + '.attn.to_out.0.weight'), None, dtype))
+
+        for st in self.stages:
+            for pre, enc in ((st.enc_prefix, True), (st.dec_prefix, False)):
+                if st.kind == 'residual':
+                    residual_unit(pre)
+                elif st.kind == 'consecutive_residual':
+                    for j in range(st.n):
+                        residual_unit(f'{pre}.{j}')
+                elif st.kind == 'compress_space':
+                    if enc:
+                        w = f(pre + '.conv.weight')
+                        put(pre, P.pack_conv3d(w[:, :, None], f(pre + '.conv.bias'), dtype))
+                    else:
+                        put(pre, P.pack_shuffle_up(f(pre + '.net.0.weight').flatten(1), f(pre + '.net.0.bias'), dtype, 4))
+                elif st.kind == 'compress_time':
+                    if enc:
+                        w = f(pre + '.conv.weight')
+                        put(pre, P.pack_conv3d(w[:, :, :, None, None], f(pre + '.conv.bias'), dtype))
+                    else:
+                        put(pre, P.pack_shuffle_up(f(pre + '.net.0.weight').flatten(1), f(pre + '.net.0.bias'), dtype, 2))
+                elif st.kind == 'attend_space':
+                    attention(pre + '.0.fn', st.dim, False)
+                    feed_forward(pre + '.1.fn', st.dim, False)
+                elif st.kind == 'linear_attend_space':
+                    linear_attention(pre + '.0.fn', st.dim)
+                    feed_forward(pre + '.1.fn', st.dim, False)
+                elif st.kind == 'attend_time':
+                    attention(pre + '.0.fn.fn', st.dim, True)
+                    feed_forward(pre + '.1.fn.fn', st.dim, True)
+
+        # quantizer (fp32 weights; per-token wave kernels)
+        self.latent_dim = self.stages[-1].dim_out if self.stages else cfg['init_dim']
+        self.use_fsq = bool(cfg['use_fsq'])
+        self.ncb = cfg['num_codebooks']
+        if self.use_fsq:
+            levels = list(cfg['fsq_levels'])
+            self.cb_dim = len(levels)
+            L = torch.tensor(levels, dtype=torch.int32)
+            half_l = (L - 1) * (1 + 1e-3) / 2
+            offset = torch.where(L % 2 == 0, 0.5, 0.0)
+            self.fsq = dict(levels=dev(L), basis=dev(torch.cumprod(torch.tensor([1] + levels[:-1]), dim=0, dtype=torch.int32)),
+                            half_l=dev(half_l.float()), offset=dev(offset.float()), shift=dev((offset / half_l).atanh().float()),
+                            half_w=dev((L // 2).float()))
+        else:
+            self.cb_dim = int(math.log2(cfg['codebook_size']))
+        cbt = self.cb_dim * self.ncb
+        if 'quantizers.project_in.weight' in sd:
+            self.q_w_in, self.q_b_in = dev(f('quantizers.project_in.weight').contiguous()), dev(f('quantizers.project_in.bias'))
+            self.q_w_out, self.q_b_out = dev(f('quantizers.project_out.weight').contiguous()), dev(f('quantizers.project_out.bias'))
+        else:   # dim == codebook dims: identity projections
+            eye = torch.eye(cbt)
+            self.q_w_in, self.q_b_in, self.q_w_out, self.q_b_out = dev(eye), dev(torch.zeros(cbt)), dev(eye.clone()), dev(torch.zeros(cbt))
+
+
+class _Arena:
+    """size-keyed recycling of plan buffers (static addresses; liveness handled by the builder)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.free: Dict[tuple, list] = {}
+        self.total_bytes = 0
+
+    def get(self, numel, dtype):
+        key = (int(numel), dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        self.total_bytes += int(numel) * torch.empty((), dtype=dtype).element_size()
+        return self.ops.empty((int(numel),), dtype)
+
+    def put(self, t):
+        self.free.setdefault((t.numel(), t.dtype), []).append(t)
+
+
+class Act:
+    """an NDHWC activation: flat tensor + geometry."""
+    __slots__ = ('t', 'B', 'T', 'H', 'W', 'C')
+
+    def __init__(self, t, B, T, H, W, C):
+        self.t, self.B, self.T, self.H, self.W, self.C = t, B, T, H, W, C
+
+    @property
+    def rows(self):
+        return self.B * self.T * self.H * self.W
+
+
+class Plan:
+    def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False):
+        self.pm, self.ops, self.cfg = pm, pm.ops, pm.cfg
+        self.dtype, self.dt = pm.dtype, pm.dt
+        self.B, self.T, self.H, self.W = B, T, H, W
+        self.arena = _Arena(self.ops)
+        self.tdf = 2 ** sum(s.kind == 'compress_time' for s in pm.stages)
+        self.time_padding = self.tdf - 1
+        self.want_prequant = want_prequant
+        self.step_names: List[str] = []
+        self.step_flops: Dict[int, float] = {}      # id(step) -> algorithmic FLOPs (conv launches)
+        ch = self.cfg['channels']
+        ops = self.ops
+        # static I/O
+        self.video_in = ops.empty((B, ch, T, H, W), torch.float32)
+        self.recon = ops.empty((B, ch, T, H, W), torch.float32)
+        # ---- encode
+        self.enc_steps: List = []
+        x = self._lower_encode(self.enc_steps)
+        self.latent = x
+        # ---- quantize
+        self.q_steps: List = []
+        self.ids = ops.empty((x.rows, pm.ncb), torch.int32 if pm.use_fsq else torch.int64)
+        self.prequant = ops.empty((x.rows, pm.cb_dim * pm.ncb), torch.float32) if want_prequant else None
+        q = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
+        if pm.use_fsq:
+            self.q_steps.append(ops.fsq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, self.ids,
+                                        self.prequant, x.rows, x.C, pm.cb_dim, pm.ncb))
+        else:
+            self.q_steps.append(ops.lfq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, q.t, self.ids, self.prequant,
+                                        x.rows, x.C, pm.cb_dim, pm.ncb, self.cfg['lfq_soft_clamp_input_value'] or 0., 1.))
+        self.quantized = q
+        # ---- ids -> quantized (decode_from_code_indices)
+        self.ids_in = ops.empty((x.rows, pm.ncb), torch.int32 if pm.use_fsq else torch.int64)
+        if pm.use_fsq:
+            self.codes_steps = [ops.fsq_codes(self.dt, self.ids_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, x.rows, x.C, pm.cb_dim, pm.ncb)]
+        else:
+            self.codes_steps = [ops.lfq_codes(self.dt, self.ids_in, pm.q_w_out, pm.q_b_out, q.t, x.rows, x.C, pm.cb_dim, pm.ncb, 1.)]
+        # ---- decode
+        self.dec_steps: List = []
+        self._lower_decode(self.dec_steps, q)
+
+    # ------------------------------------------------------------------ helpers
+    def _conv(self, steps, name, pc: P.PackedConv, x: Act, *, To=None, Ho=None, Wo=None, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
+              check_bounds=True, act=P.ACT_NONE, store=P.STORE_ROWS, shuffle=(1, 1, 1), crop_t=0, out_c=None, rowscale=None,
+              residual=None, out_t=None, in_bytes=None, in_geom=None):
+        B, Ti, Hi, Wi, Ci = in_geom if in_geom is not None else (x.B, x.T, x.H, x.W, x.C)
+        To = Ti if To is None else To
+        Ho = Hi if Ho is None else Ho
+        Wo = Wi if Wo is None else Wo
+        rt, rh, rw = shuffle
+        if out_c is None:
+            out_c = pc.co // 2 if act == P.ACT_GEGLU else (pc.co // (rt * rh * rw) if store == P.STORE_SHUFFLE else pc.co)
+        d = dict(dtype=self.dt, B=B, Ti=Ti, Hi=Hi, Wi=Wi, Ci=Ci, To=To, Ho=Ho, Wo=Wo, co=pc.co, co_pad=pc.co_pad, st=st, sh=sh,
+                 sw=sw, pt=pt, ph=ph, pw=pw, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes,
+                 check_bounds=int(check_bounds), act=act, store=store, rt=rt, rh=rh, rw=rw, crop_t=crop_t, out_c=out_c, splitk=0)
+        rows_out = B * To * Ho * Wo
+        if store == P.STORE_NCTHW_F32:
+            assert out_t is not None
+            out = None
+        else:
+            out_rows = rows_out * rt * rh * rw
+            if out_t is None:
+                out_t = self.arena.get(out_rows * out_c, self.dtype)
+            out = Act(out_t, B, To * rt, Ho * rh, Wo * rw, out_c)
+        segs = pc.segs_tensor(Hi, Wi, Ci, self.ops.device)
+        wsb = self.ops.conv_workspace_bytes(d)
+        ws = self.arena.get((wsb + 3) // 4, torch.float32) if wsb > 0 else None
+        if in_bytes is None:
+            in_bytes = x.t.numel() * x.t.element_size()
+        steps.append(self.ops.conv(d, x.t, in_bytes, pc.wp, segs, pc.bias, rowscale, None if residual is None else residual.t,
+                                   out_t, ws))
+        steps[-1].label = name
+        self.step_flops[id(steps[-1])] = 2.0 * rows_out * pc.co_real * pc.k_real
+        self.step_names.append(name)
+        if ws is not None:
+            self.arena.put(ws)
+        return out
+
+    def _rms(self, steps, x: Act, shift: bool):
+        rs = self.arena.get(x.rows, torch.float32)
+        steps.append(self.ops.rms_rowscale(self.dt, x.t, rs, x.rows, x.C, x.H * x.W if shift else 0, x.T))
+        self.step_names.append('rms_rowscale')
+        return rs
+
+    def _residual_unit(self, steps, pre, x: Act) -> Act:
+        pm, ops = self.pm, self.ops
+        k = self.cfg['residual_conv_kernel_size']
+        y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
+        y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
+        self.arena.put(y1.t)
+        frames, Pn, C = x.B * x.T, x.H * x.W, x.C
+        nchunk = max(1, min(Pn // 64 if Pn >= 64 else 1, -(-1024 // frames)))
+        part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
+        gate = self.arena.get(frames * C, torch.float32)
+        steps.append(ops.se_pool(self.dt, y2.t, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']), part, frames, Pn, C, nchunk))
+        steps.append(ops.se_gate(part, pm.f32[pre + '.se.w1'], pm.f32[pre + '.se.b1'], pm.f32[pre + '.se.w2'], pm.f32[pre + '.se.b2'],
+                                 gate, frames, C, se_hidden(C), nchunk))
+        out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
+        steps.append(ops.se_apply(self.dt, y2.t, gate, x.t, out.t, frames, Pn, C))
+        self.step_names += ['se_pool', 'se_gate', 'se_apply']
+        for t in (part, gate, y2.t, x.t):
+            self.arena.put(t)
+        return out
+
+    def _feed_forward(self, steps, pre, x: Act, shift: bool) -> Act:
+        pm = self.pm
+        rs = self._rms(steps, x, shift)
+        kw = dict(pt=1, check_bounds=True) if shift else dict(check_bounds=False)
+        h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], x, act=P.ACT_GEGLU, rowscale=rs, **kw)
+        self.arena.put(rs)
+        out = self._conv(steps, pre + '.ff2', pm.convs[pre + '.ff2'], h, residual=x, check_bounds=False)
+        self.arena.put(h.t)
+        self.arena.put(x.t)
+        return out
+
+    def _attention(self, steps, pre, x: Act, time_axis: bool) -> Act:
+        pm, ops, cfg = self.pm, self.ops, self.cfg
+        heads, dh = cfg['attn_heads'], cfg['attn_dim_head']
+        rs = self._rms(steps, x, time_axis)
+        kw = dict(pt=1, check_bounds=True) if time_axis else dict(check_bounds=False)
+        qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], x, rowscale=rs, **kw)
+        self.arena.put(rs)
+        ao = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
+        mem = pm.f32[pre + '.mem_kv']
+        hw = x.H * x.W
+        if time_axis:
+            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, x.B * hw, x.T, heads, dh, mem.shape[2], True, hw, x.T * hw, hw))
+        else:
+            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, x.B * x.T, hw, heads, dh, mem.shape[2], False, 1, hw, 1))
+        self.step_names.append('attention')
+        self.arena.put(qkv.t)
+        out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], ao, residual=x, check_bounds=False)
+        self.arena.put(ao.t)
+        self.arena.put(x.t)
+        return out
+
+    def _linear_attention(self, steps, pre, x: Act) -> Act:
+        pm, ops, cfg = self.pm, self.ops, self.cfg
+        heads, dh = cfg['linear_attn_heads'], cfg['linear_attn_dim_head']
+        assert dh == 8, 'Taylor attention kernel is built for dim_head 8 (reference default, magvit2_pytorch.py:1079)'
+        rs = self._rms(steps, x, False)
+        q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rowscale=rs, check_bounds=False)
+        kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rowscale=rs, check_bounds=False)
+        self.arena.put(rs)
+        frames, n = x.B * x.T, x.H * x.W
+        nchunk = max(1, min(n // 32 if n >= 32 else 1, -(-512 // frames)))
+        part = self.arena.get(frames * nchunk * heads * 657, torch.float32)
+        kvsum = self.arena.get(frames * heads * 657, torch.float32)
+        o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
+        steps.append(ops.taylor_kv(self.dt, kv.t, part, frames, n, heads, nchunk))
+        steps.append(ops.taylor_apply(self.dt, q.t, part, o.t, kvsum, frames, n, heads, nchunk))
+        self.step_names += ['taylor_kv', 'taylor_apply']
+        for t in (part, kvsum, q.t, kv.t):
+            self.arena.put(t)
+        out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], o, residual=x, check_bounds=False)
+        self.arena.put(o.t)
+        self.arena.put(x.t)
+        return out
+
+    # ------------------------------------------------------------------ encode / decode lowering
+    def _lower_encode(self, steps) -> Act:
+        pm, ops, cfg = self.pm, self.ops, self.cfg
+        B, T, H, W = self.B, self.T, self.H, self.W
+        kt, kh, kw = cfg['input_conv_kernel_size']
+        assert kh == kw and kh % 2 == 1
+        pad_t, pad_hw, cp = self.time_padding + (kt - 1), kh // 2, pm.c_in_pad
+        Tp, Hp, Wp = T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw
+        tail = 64 * cp
+        padded = self.arena.get(B * Tp * Hp * Wp * cp + tail, self.dtype)
+        steps.append(ops.video_to_ndhwc(self.dt, self.video_in, padded, B, cfg['channels'], T, H, W, pad_t, pad_hw, cp, tail))
+        self.step_names.append('video_to_ndhwc')
+        xin = Act(padded, B, Tp, Hp, Wp, cp)
+        x = self._conv(steps, 'conv_in', pm.convs['conv_in'], xin, To=T + self.time_padding, Ho=H, Wo=W, check_bounds=False,
+                       in_bytes=padded.numel() * padded.element_size())
+        self.arena.put(padded)
+        for st in pm.stages:
+            x = self._stage(steps, st, st.enc_prefix, x, True)
+        return x
+
+    def _stage(self, steps, st: Stage, pre, x: Act, enc: bool) -> Act:
+        pm = self.pm
+        if st.kind == 'residual':
+            return self._residual_unit(steps, pre, x)
+        if st.kind == 'consecutive_residual':
+            for j in range(st.n):
+                x = self._residual_unit(steps, f'{pre}.{j}', x)
+            return x
+        if st.kind == 'compress_space':
+            if enc:
+                out = self._conv(steps, pre, pm.convs[pre], x, Ho=(x.H + 2 - 3) // 2 + 1, Wo=(x.W + 2 - 3) // 2 + 1, sh=2, sw=2, ph=1, pw=1)
+            else:
+                out = self._conv(steps, pre, pm.convs[pre], x, act=P.ACT_SILU, store=P.STORE_SHUFFLE, shuffle=(1, 2, 2), check_bounds=False)
+            self.arena.put(x.t)
+            return out
+        if st.kind == 'compress_time':
+            if enc:
+                out = self._conv(steps, pre, pm.convs[pre], x, To=(x.T - 1) // 2 + 1, st=2, pt=2)
+            else:
+                out = self._conv(steps, pre, pm.convs[pre], x, act=P.ACT_SILU, store=P.STORE_SHUFFLE, shuffle=(2, 1, 1), check_bounds=False)
+            self.arena.put(x.t)
+            return out
+        if st.kind == 'attend_space':
+            x = self._attention(steps, pre + '.0.fn', x, False)
+            return self._feed_forward(steps, pre + '.1.fn', x, False)
+        if st.kind == 'linear_attend_space':
+            x = self._linear_attention(steps, pre + '.0.fn', x)
+            return self._feed_forward(steps, pre + '.1.fn', x, False)
+        if st.kind == 'attend_time':
+            x = self._attention(steps, pre + '.0.fn.fn', x, True)
+            return self._feed_forward(steps, pre + '.1.fn.fn', x, True)
+        raise ValueError(st.kind)
+
+    def _lower_decode(self, steps, q: Act):
+        pm, cfg = self.pm, self.cfg
+        # The decoder recycles its input buffer like any other activation: every decode is preceded by a
+        # step that rewrites `quantized` (the quantizer, the ids->codes kernel, or an explicit copy).
+        x = Act(q.t, q.B, q.T, q.H, q.W, q.C)
+        for st in reversed(pm.stages):
+            x = self._stage(steps, st, st.dec_prefix, x, False)
+        kt, kh, kw = cfg['output_conv_kernel_size']
+        self._conv(steps, 'conv_out', pm.convs['conv_out'], x, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
+                   crop_t=self.time_padding, out_t=self.recon, out_c=4)
+
+    # ------------------------------------------------------------------ execution
+    def run(self, steps, stream=None):
+        s = self.ops.current_stream() if stream is None else stream
+        for st in steps:
+            st(s)

@@ -1,0 +1,358 @@
+"""
+``VideoTokenizer`` — drop-in for ``magvit2_pytorch.VideoTokenizer`` on the encode -> quantize -> decode
+hot path (reference magvit2_pytorch.py:1045-1720), executing on MI355X through libmv2_hip.so.
+
+Kept from the reference: the keyword-only constructor and its layer-spec tuple grammar, the
+``state_dict`` key names and shapes (checkpoints load both ways), and the method surface
+``encode / decode / tokenize / decode_from_code_indices / forward`` with the same tensor conventions
+(NCTHW video or NCHW image in, ids ``(B, T', H', W')`` int64 for LFQ / int32 for FSQ) and the same
+assertions.  Training losses, GAN / VGG, conditioning and gateloop layers are out of scope here and
+raise ``NotImplementedError``.
+
+Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode) or
+torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode).  Default: bf16 when called
+under ``torch.autocast`` or after ``.bfloat16()``, else fp32 — mirroring how the reference gets its
+precision from the caller.
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import spec as S
+from .plan import PackedModel, Plan
+
+__version__ = '0.1.0'
+
+
+def _exists(v):
+    return v is not None
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
+    parts = dotted.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class VideoTokenizer(nn.Module):
+    def __init__(
+        self,
+        *,
+        image_size,
+        layers: Tuple = ('residual', 'residual', 'residual'),
+        residual_conv_kernel_size=3,
+        num_codebooks=1,
+        codebook_size: Optional[int] = None,
+        channels=3,
+        init_dim=64,
+        max_dim=float('inf'),
+        dim_cond=None,
+        dim_cond_expansion_factor=4.,
+        input_conv_kernel_size: Tuple[int, int, int] = (7, 7, 7),
+        output_conv_kernel_size: Tuple[int, int, int] = (3, 3, 3),
+        pad_mode: str = 'constant',
+        lfq_entropy_loss_weight=0.1,
+        lfq_commitment_loss_weight=1.,
+        lfq_diversity_gamma=2.5,
+        lfq_spherical=False,
+        quantizer_aux_loss_weight=1.,
+        lfq_soft_clamp_input_value=10.,
+        lfq_activation=None,
+        use_fsq=False,
+        fsq_levels=None,
+        attn_dim_head=32,
+        attn_heads=8,
+        attn_dropout=0.,
+        linear_attn_dim_head=8,
+        linear_attn_heads=16,
+        vgg=None,
+        vgg_weights=None,
+        perceptual_loss_weight=1e-1,
+        discr_kwargs: Optional[dict] = None,
+        multiscale_discrs: Tuple = tuple(),
+        use_gan=True,
+        adversarial_loss_weight=1.,
+        grad_penalty_loss_weight=10.,
+        multiscale_adversarial_loss_weight=1.,
+        flash_attn=True,
+        separate_first_frame_encoding=False,
+        seed: Optional[int] = None,
+    ):
+        super().__init__()
+        _locals = {k: v for k, v in locals().items() if k not in ('self', '__class__', 'seed')}
+        try:
+            self._configs = pickle.dumps(_locals)            # reference: magvit2_pytorch.py:1097-1100
+        except Exception:
+            self._configs = None
+
+        if _exists(dim_cond):
+            raise NotImplementedError('conditioned layers (dim_cond) are outside the hot-path scope of this build')
+        if separate_first_frame_encoding:
+            raise NotImplementedError('separate_first_frame_encoding is outside the hot-path scope of this build')
+        if pad_mode != 'constant':
+            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        if lfq_spherical:
+            raise NotImplementedError('lfq_spherical is not implemented')
+        if not use_fsq:                                       # reference: magvit2_pytorch.py:1359
+            assert _exists(codebook_size) and not _exists(fsq_levels), \
+                'if use_fsq is set to False, `codebook_size` must be set (and not `fsq_levels`)'
+        else:                                                 # reference: magvit2_pytorch.py:1376
+            assert not _exists(codebook_size) and _exists(fsq_levels), \
+                'if use_fsq is set to True, `fsq_levels` must be set (and not `codebook_size`)'
+        assert attn_dim_head == 32, 'softmax-attention kernel is built for dim_head 32 (reference default)'
+
+        self.cfg = S.make_cfg(
+            image_size=image_size, layers=tuple(layers), residual_conv_kernel_size=residual_conv_kernel_size,
+            num_codebooks=num_codebooks, codebook_size=codebook_size, channels=channels, init_dim=init_dim, max_dim=max_dim,
+            input_conv_kernel_size=tuple(input_conv_kernel_size), output_conv_kernel_size=tuple(output_conv_kernel_size),
+            lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
+            fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
+            linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads)
+
+        self.channels = channels
+        self.image_size = image_size
+        self.use_fsq = use_fsq
+        self.separate_first_frame_encoding = False
+        self.has_cond = False
+        stages = S.parse_layers(self.cfg['layers'], init_dim, max_dim)    # raises ValueError on unknown layer (:1312)
+        self.time_downsample_factor = 2 ** sum(s.kind == 'compress_time' for s in stages)
+        self.time_padding = self.time_downsample_factor - 1
+        fmap = image_size
+        for s in stages:
+            if s.kind == 'compress_space':
+                assert fmap > 1
+                fmap //= 2
+        self.fmap_size = fmap
+
+        # parameters under the reference's names
+        gen = torch.Generator().manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        self._param_names = []
+        for ps in S.param_specs(self.cfg):
+            _register(self, ps.name, S.init_tensor(ps, gen), ps.buffer)
+            self._param_names.append(ps.name)
+        self.register_buffer('zero', torch.tensor(0.), persistent=False)
+
+        self.compute_dtype: Optional[torch.dtype] = None      # None = infer (see module docstring)
+        self.use_hip_graph = True
+        self._ops = None
+        self._packed: Dict[tuple, PackedModel] = {}
+        self._plans: Dict[tuple, Plan] = {}
+        self._graphs: Dict[tuple, object] = {}
+        self._weights_version = 0
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def device(self):
+        return self.zero.device
+
+    def state_dict(self, *args, **kwargs):
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts a reference state_dict unchanged: discriminator / VGG entries are ignored."""
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith('discr.') or k.startswith('vgg.') or k.startswith('multiscale_discrs.'))}
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self.refresh_weights()
+        return out
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place: drops packed weights, plans and graphs."""
+        self._weights_version += 1
+        self._packed.clear()
+        self._plans.clear()
+        self._graphs.clear()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if hasattr(self, '_packed'):
+            self.refresh_weights()
+        return out
+
+    def save(self, path, overwrite=True):
+        from pathlib import Path
+        path = Path(path)
+        assert overwrite or not path.exists(), f'{str(path)} already exists'
+        torch.save(dict(model_state_dict=self.state_dict(), version=__version__, config=self._configs), str(path))
+
+    def load(self, path, strict=True):
+        pkg = torch.load(str(path), map_location='cpu', weights_only=False)
+        state_dict = pkg.get('model_state_dict')
+        assert _exists(state_dict)
+        self.load_state_dict(state_dict, strict=strict)
+
+    @classmethod
+    def init_and_load_from(cls, path, strict=True):
+        pkg = torch.load(str(path), map_location='cpu', weights_only=False)
+        assert 'config' in pkg, 'model configs were not found in this saved checkpoint'
+        config = pickle.loads(pkg['config'])
+        tok = cls(**config)
+        tok.load(path, strict=strict)
+        return tok
+
+    # ------------------------------------------------------------------ backend / plans
+    def _set_backend(self, ops):
+        """test hook: inject an ops backend (the CPU emulation of the kernel semantics)."""
+        self._ops = ops
+        self.refresh_weights()
+
+    def _backend(self):
+        if self._ops is None:
+            from .ops_hip import HipOps           # raises if the library / a HIP device is missing: no CPU fallback
+            dev = self.device
+            if dev.type != 'cuda':
+                raise RuntimeError('VideoTokenizer parameters are on %s: move the module to a HIP device (.cuda()); '
+                                   'the product path has no CPU fallback' % dev)
+            self._ops = HipOps(dev)
+        return self._ops
+
+    def _dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled() or self.conv_in.conv.weight.dtype == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    def _plan(self, B, T, want_prequant=False) -> Plan:
+        ops = self._backend()
+        dt = self._dtype()
+        kpm = (dt, self._weights_version)
+        if kpm not in self._packed:
+            sd = {n: self.get_parameter(n) if n != 'quantizers.mask' else self.get_buffer(n) for n in self._param_names}
+            self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops)
+        kp = (dt, self._weights_version, B, T, want_prequant)
+        if kp not in self._plans:
+            self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant)
+        return self._plans[kp], kp
+
+    def _run(self, plan: Plan, key, which: str, step_lists):
+        """Runs step lists on the current stream; on HIP the sequence is captured into a graph on its
+        second use (first use runs eagerly: it also performs one-time kernel attribute setup)."""
+        ops = plan.ops
+        gkey = (key, which)
+        if getattr(ops, 'name', '') != 'hip' or not self.use_hip_graph:
+            for steps in step_lists:
+                plan.run(steps)
+            return
+        g = self._graphs.get(gkey)
+        if g is None:
+            for steps in step_lists:
+                plan.run(steps)
+            self._graphs[gkey] = 'warm'
+            return
+        if g == 'warm':
+            torch.cuda.synchronize(ops.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for steps in step_lists:
+                    plan.run(steps)
+            self._graphs[gkey] = graph
+            g = graph
+        g.replay()
+
+    # ------------------------------------------------------------------ helpers
+    def _check_video(self, video_or_images):
+        assert video_or_images.ndim in {4, 5}                                     # reference :1675
+        assert video_or_images.shape[-2:] == (self.image_size, self.image_size)   # reference :1677
+        video = video_or_images.unsqueeze(2) if video_or_images.ndim == 4 else video_or_images
+        frames = video.shape[2]
+        assert (frames - 1) % self.time_downsample_factor == 0, \
+            f'number of frames {frames} minus the first frame ({frames - 1}) must be divisible by the total downsample factor across time {self.time_downsample_factor}'
+        assert video.shape[1] == self.channels
+        return video
+
+    def _ids_out(self, plan: Plan):
+        x = plan.latent
+        ids = plan.ids.reshape(x.B, x.T, x.H, x.W, plan.pm.ncb).clone()
+        return ids.squeeze(-1) if plan.pm.ncb == 1 else ids
+
+    def _to_ncthw(self, act, dtype=None):
+        t = act.t[: act.rows * act.C].reshape(act.B, act.T, act.H, act.W, act.C).permute(0, 4, 1, 2, 3)
+        return t.contiguous() if dtype is None else t.to(dtype).contiguous()
+
+    # ------------------------------------------------------------------ API
+    @torch.no_grad()
+    def encode(self, video, quantize=False, cond=None, video_contains_first_frame=True):
+        assert cond is None and video_contains_first_frame, 'conditioning / headless videos are out of scope'
+        video = self._check_video(video)
+        plan, key = self._plan(video.shape[0], video.shape[2])
+        plan.video_in.copy_(video)
+        if not quantize:
+            self._run(plan, key, 'enc', [plan.enc_steps])
+            return self._to_ncthw(plan.latent)
+        self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
+        q = self._to_ncthw(plan.quantized)
+        if self.use_fsq:
+            return q, self._ids_out(plan)
+        return q, self._ids_out(plan), self.zero
+
+    @torch.no_grad()
+    def decode(self, quantized, cond=None, video_contains_first_frame=True):
+        assert cond is None and video_contains_first_frame
+        B, C, Tl, Hl, Wl = quantized.shape
+        T = (Tl - 1) * self.time_downsample_factor + 1
+        plan, key = self._plan(B, T)
+        q = plan.quantized
+        assert (C, Tl, Hl, Wl) == (q.C, q.T, q.H, q.W)
+        q.t[: q.rows * q.C].reshape(B, Tl, Hl, Wl, C).copy_(quantized.permute(0, 2, 3, 4, 1))
+        self._run(plan, key, 'dec', [plan.dec_steps])
+        return plan.recon.clone()
+
+    @torch.no_grad()
+    def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):
+        assert codes.dtype in (torch.long, torch.int32)                           # reference :1585
+        assert cond is None and video_contains_first_frame
+        ncb = self.cfg['num_codebooks']
+        if codes.ndim == 2:
+            video_code_len = codes.shape[-1]
+            assert video_code_len % (self.fmap_size ** 2) == 0, \
+                f'flattened video ids must have a length ({video_code_len}) that is divisible by the fmap size ({self.fmap_size}) squared ({self.fmap_size ** 2})'
+            codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
+        B, Tl = codes.shape[0], codes.shape[1]
+        T = (Tl - 1) * self.time_downsample_factor + 1
+        plan, key = self._plan(B, T)
+        plan.ids_in.copy_(codes.reshape(-1, ncb))
+        self._run(plan, key, 'codes+dec', [plan.codes_steps, plan.dec_steps])
+        return plan.recon.clone()
+
+    @torch.no_grad()
+    def tokenize(self, video):
+        self.eval()
+        return self.forward(video, return_codes=True)
+
+    def forward(self, video_or_images, cond=None, return_loss=False, return_codes=False, return_recon=False,
+                return_discr_loss=False, return_recon_loss_only=False, apply_gradient_penalty=True,
+                video_contains_first_frame=True, adversarial_loss_weight=None, multiscale_adversarial_loss_weight=None,
+                return_prequant=False):
+        assert (return_loss + return_codes + return_discr_loss) <= 1              # reference :1674
+        if return_loss or return_discr_loss:
+            raise NotImplementedError('training losses are outside the hot-path scope of this build (SURVEY.md §8f)')
+        assert cond is None and video_contains_first_frame
+        video = self._check_video(video_or_images)
+        with torch.no_grad():
+            plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
+            plan.video_in.copy_(video)
+            if return_codes and not return_recon:
+                self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
+                codes = self._ids_out(plan)
+                return (codes, plan.prequant.clone()) if return_prequant else codes
+            self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
+            recon = plan.recon.clone()
+            if video_or_images.ndim == 4:
+                pass   # the reference also returns a 5-D (T = 1) reconstruction for image input
+            if return_codes:
+                codes = self._ids_out(plan)
+                return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
+            if return_recon_loss_only:
+                return torch.nn.functional.mse_loss(video.float(), recon), recon
+            return recon

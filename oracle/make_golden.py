@@ -1,0 +1,95 @@
+"""
+TEST INFRASTRUCTURE.  Generates tests/golden/*.npz by running the REFERENCE ITSELF
+(/root/reference, loaded by oracle/ref_loader.py) on CPU fp32.  Run in the authoring container:
+
+    python -m oracle.make_golden
+
+Weights are not stored (config 2 alone is 471 MB): they are re-created on every box by
+``magvit2_pytorch_amd.spec.init_state_dict(cfg, seed, randomize_se=True)`` — a pure function of the
+torch CPU generator — and pinned by the SHA-256 stored in the fixture; the input video likewise.
+Each fixture holds: the config (json), seeds, sha256 of weights and input, the reference's code ids,
+its reconstruction (full for small cases, a strided sample + moments for config 2) and its
+``decode_from_code_indices`` output.  LFQ / FSQ / Taylor arithmetic inside the reference run comes
+from oracle/thirdparty.py (parity unpinned for those three modules, see its header).
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from magvit2_pytorch_amd.spec import README_LAYERS, init_state_dict, make_cfg   # noqa: E402
+from oracle.ref_loader import make_reference_tokenizer                          # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+
+CASES = {
+    # name: (ctor kwargs, input shape, weight seed, data seed, recon stride)
+    'small_lfq': (dict(image_size=32, init_dim=8, max_dim=32, codebook_size=256, layers=README_LAYERS), (2, 3, 9, 32, 32), 0, 1, 1),
+    'small_fsq': (dict(image_size=32, init_dim=8, max_dim=32, use_fsq=True, fsq_levels=[8, 5, 5, 5], layers=README_LAYERS), (2, 3, 5, 32, 32), 2, 3, 1),
+    'small_image': (dict(image_size=32, init_dim=8, max_dim=32, codebook_size=256, layers=README_LAYERS), (2, 3, 32, 32), 0, 4, 1),
+    'mid_lfq': (dict(image_size=64, init_dim=16, max_dim=128, codebook_size=1024, layers=README_LAYERS), (1, 3, 9, 64, 64), 5, 6, 1),
+    # BASELINE.json configs[0] and configs[1]
+    'cfg1_image128': (dict(image_size=128, init_dim=32, max_dim=512, codebook_size=512, layers=README_LAYERS), (1, 3, 128, 128), 0, 1, 2),
+    'cfg2_video128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (1, 3, 17, 128, 128), 0, 1, 4),
+}
+
+
+def sha_tensors(tensors) -> str:
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def weights_sha(sd) -> str:
+    return sha_tensors([sd[k] for k in sorted(sd)])
+
+
+def make_input(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def generate(name):
+    kw, shape, wseed, dseed, stride = CASES[name]
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=wseed, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith('discr.') for m in missing), (missing, unexpected)
+    video = make_input(shape, dseed)
+    with torch.no_grad():
+        codes, recon = ref(video, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes)
+        tok = ref.tokenize(video)
+    assert torch.equal(tok, codes)
+    assert torch.equal(dec, recon)          # README round trip (README.md:85-90) holds exactly
+    r = recon.numpy()
+    out = dict(
+        cfg=json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}),
+        shape=np.array(shape), weight_seed=wseed, data_seed=dseed, stride=stride,
+        weights_sha256=weights_sha(sd), input_sha256=sha_tensors([video]),
+        codes=codes.numpy(), recon_sample=r[..., ::stride, ::stride].astype(np.float32),
+        recon_mean=np.float64(r.astype(np.float64).mean()), recon_std=np.float64(r.astype(np.float64).std()),
+        recon_abs_sum=np.float64(np.abs(r.astype(np.float64)).sum()),
+        torch_version=torch.__version__,
+    )
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: codes {tuple(codes.shape)} {codes.dtype}, recon {tuple(recon.shape)} std {recon.std():.4f} -> {path} '
+          f'({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+if __name__ == '__main__':
+    for n in (sys.argv[1:] or CASES):
+        generate(n)

@@ -1,0 +1,335 @@
+"""
+TEST INFRASTRUCTURE — not product code (only tests/ may import it).
+
+``CpuOps``: a plain-torch CPU emulation of the *kernel-level* semantics declared in include/mv2.h
+(packed weights, K-program segments, epilogues, NDHWC addressing).  It has the same method surface
+as ``magvit2_pytorch_amd.ops_hip.HipOps`` and is injected into the façade by tests to
+  (1) validate the host logic — weight packing, K programs, plan lowering, buffer recycling — against
+      the reference on CPU where no GPU exists, and
+  (2) serve as the per-kernel expected value in the ``-m gpu`` unit tests of each C-ABI entry point.
+It is deliberately written from the header's wording (generic gathers, no conv library calls), so a
+packing bug cannot cancel against a matching bug here.  fp64 accumulation, results rounded to the
+storage dtype like the kernels' stores.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
+STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32 = 0, 1, 2
+
+
+def _esize(t):
+    return t.element_size()
+
+
+class CpuOps:
+    name = 'cpu-emulation'
+    device = torch.device('cpu')
+    cus = 256
+
+    def __init__(self, acc_dtype=torch.float64):
+        self.acc = acc_dtype
+
+    def empty(self, shape, dtype):
+        # NaN-poison float buffers so that any read-before-write in a plan is caught
+        if dtype.is_floating_point:
+            return torch.full(shape, float('nan'), dtype=dtype)
+        return torch.zeros(shape, dtype=dtype)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def to_device(self, t):
+        return t
+
+    def current_stream(self):
+        return 0
+
+    def synchronize(self):
+        pass
+
+    # ------------------------------------------------------------------ conv
+    def conv_workspace_bytes(self, d):
+        return 0
+
+    def conv(self, d, x, in_bytes, wp, segs, bias, rowscale, residual, out, ws):
+        d = dict(d)
+        acc = self.acc
+
+        def step(stream):
+            es = _esize(x)
+            kel = 128 // es                       # elements per K step
+            seg_el = d['seg_bytes'] // es
+            per_step = 128 // d['seg_bytes']
+            B, Ti, Hi, Wi, Ci = d['B'], d['Ti'], d['Hi'], d['Wi'], d['Ci']
+            To, Ho, Wo = d['To'], d['Ho'], d['Wo']
+            M = B * To * Ho * Wo
+            m = torch.arange(M)
+            wo = m % Wo; r = m // Wo
+            ho = r % Ho; r = r // Ho
+            to = r % To; b = r // To
+            t_in = to * d['st'] - d['pt']; h_in = ho * d['sh'] - d['ph']; w_in = wo * d['sw'] - d['pw']
+            rowbase = (((b * Ti + t_in) * Hi + h_in) * Wi + w_in) * Ci
+            flat = x.reshape(-1).to(acc)
+            assert in_bytes <= x.numel() * es
+            nsteps = d['nsteps']
+            W = wp.to(acc)                         # (nsteps, co_pad, kel)
+            D = torch.zeros(M, d['co_pad'], dtype=acc)
+            sg = segs.reshape(-1, 2)
+            chunk = max(1, (1 << 22) // max(1, seg_el))
+            for s in range(nsteps):
+                for q in range(per_step):
+                    off, sel = int(sg[s * per_step + q, 0]), int(sg[s * per_step + q, 1]) & 0xffffffff
+                    if sel & 0x80000000:
+                        continue
+                    it = (sel & 0xff).bit_length() - 1
+                    ih = ((sel >> 8) & 0xff).bit_length() - 1
+                    iw = ((sel >> 16) & 0xff).bit_length() - 1
+                    if d['check_bounds']:
+                        ok = ((t_in + it >= 0) & (t_in + it < Ti) & (h_in + ih >= 0) & (h_in + ih < Hi)
+                              & (w_in + iw >= 0) & (w_in + iw < Wi))
+                    else:
+                        ok = torch.ones(M, dtype=torch.bool)
+                    wseg = W[s, :, q * seg_el:(q + 1) * seg_el]               # (co_pad, seg_el)
+                    for c0 in range(0, M, chunk):
+                        sl = slice(c0, min(M, c0 + chunk))
+                        okc = ok[sl]
+                        if not bool(okc.any()):
+                            continue
+                        idx = (rowbase[sl] + off)[:, None] + torch.arange(seg_el)[None, :]
+                        idx = torch.where(okc[:, None], idx, torch.zeros_like(idx))
+                        assert int(idx.max()) * es + es <= in_bytes, 'gather beyond in_bytes'
+                        assert int(idx.min()) >= 0
+                        a = flat[idx] * okc[:, None].to(acc)
+                        D[sl] += a @ wseg.t()
+            if rowscale is not None:
+                D = D * rowscale[:M].to(acc)[:, None]
+            if bias is not None:
+                D = D + bias.to(acc)[None, :]
+            co = d['co']
+            if d['act'] == ACT_ELU:
+                D = torch.nn.functional.elu(D)
+            elif d['act'] == ACT_SILU:
+                D = torch.nn.functional.silu(D)
+            if d['act'] == ACT_GEGLU:
+                hp = co // 2
+                Dv = D[:, :co].reshape(M, co // 64, 2, 32)
+                o = (torch.nn.functional.gelu(Dv[:, :, 1]) * Dv[:, :, 0]).reshape(M, hp)
+                out[: M * hp].copy_(o.reshape(-1).to(out.dtype))
+                return
+            if d['store'] == STORE_ROWS:
+                oc = d['out_c']
+                o = D[:, :co]
+                if residual is not None:
+                    o = o + residual[: M * oc].reshape(M, oc)[:, :co].to(acc)
+                assert oc == co
+                out[: M * oc].copy_(o.reshape(-1).to(out.dtype))
+            elif d['store'] == STORE_SHUFFLE:
+                rt, rh, rw, cq = d['rt'], d['rh'], d['rw'], d['out_c']
+                o = D[:, :co].reshape(B, To, Ho, Wo, rt, rh, rw, cq).permute(0, 1, 4, 2, 5, 3, 6, 7)
+                out[: M * co].copy_(o.reshape(-1).to(out.dtype))
+            else:
+                crop = d['crop_t']
+                o = D[:, :co].reshape(B, To, Ho, Wo, co)[:, crop:].permute(0, 4, 1, 2, 3)
+                out.copy_(o.to(out.dtype))
+        step.outs = [o for o in [out, ws] if o is not None]
+        step.what = 'conv'
+        return step
+
+    # ------------------------------------------------------------------ layout edge
+    def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
+        def step(stream):
+            Tp, Hp, Wp = T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw
+            buf = torch.zeros(B, Tp, Hp, Wp, c_pad, dtype=out.dtype)
+            buf[:, pad_t:, pad_hw:pad_hw + H, pad_hw:pad_hw + W, :Cc] = video.permute(0, 2, 3, 4, 1).to(out.dtype)
+            out[: buf.numel()].copy_(buf.reshape(-1))
+            out[buf.numel(): buf.numel() + tail_elems] = 0
+        step.outs = [o for o in [out] if o is not None]
+        step.what = 'video_to_ndhwc'
+        return step
+
+    def _shifted(self, x, rows, Cc, shift_hw, T):
+        xr = x[: rows * Cc].reshape(rows, Cc).to(self.acc)
+        if shift_hw <= 0:
+            return xr
+        prev = torch.zeros_like(xr)
+        prev[shift_hw:] = xr[:-shift_hw]
+        first = ((torch.arange(rows) // shift_hw) % T) == 0
+        prev[first] = 0
+        return torch.cat((xr[:, : Cc // 2], prev[:, Cc // 2:]), dim=1)
+
+    def rms_rowscale(self, dt, x, rs, rows, Cc, shift_hw, T):
+        def step(stream):
+            xs = self._shifted(x, rows, Cc, shift_hw, T)
+            rs[:rows].copy_((1.0 / xs.norm(dim=1).clamp(min=1e-12)).float())
+        step.outs = [o for o in [rs] if o is not None]
+        step.what = 'rms_rowscale'
+        return step
+
+    # ------------------------------------------------------------------ squeeze-excite
+    def se_pool(self, dt, y, wk, bk, part, frames, Pn, Cc, nchunk):
+        def step(stream):
+            yr = y[: frames * Pn * Cc].reshape(frames, Pn, Cc).to(self.acc)
+            logits = yr @ wk.to(self.acc) + bk
+            per = -(-Pn // nchunk)
+            pv = part[: frames * nchunk * (Cc + 2)].reshape(frames, nchunk, Cc + 2)
+            for j in range(nchunk):
+                lo, hi = j * per, min(Pn, (j + 1) * per)
+                if lo >= hi:
+                    pv[:, j, 0] = float('-inf'); pv[:, j, 1:] = 0
+                    continue
+                lg = logits[:, lo:hi]
+                mx = lg.max(dim=1).values
+                e = (lg - mx[:, None]).exp()
+                pv[:, j, 0] = mx.float()
+                pv[:, j, 1] = e.sum(dim=1).float()
+                pv[:, j, 2:] = torch.einsum('fp,fpc->fc', e, yr[:, lo:hi]).float()
+        step.outs = [o for o in [part] if o is not None]
+        step.what = 'se_pool'
+        return step
+
+    def se_gate(self, part, w1, b1, w2, b2, gate, frames, Cc, hidden, nchunk):
+        def step(stream):
+            pv = part[: frames * nchunk * (Cc + 2)].reshape(frames, nchunk, Cc + 2).to(self.acc)
+            M = pv[:, :, 0].max(dim=1).values
+            w = (pv[:, :, 0] - M[:, None]).exp()
+            S = (pv[:, :, 1] * w).sum(dim=1)
+            pooled = (pv[:, :, 2:] * w[:, :, None]).sum(dim=1) / S[:, None]
+            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc).t() + b1.to(self.acc), 0.1)
+            g = torch.sigmoid(h @ w2.to(self.acc).t() + b2.to(self.acc))
+            gate[: frames * Cc].copy_(g.reshape(-1).float())
+        step.outs = [o for o in [gate] if o is not None]
+        step.what = 'se_gate'
+        return step
+
+    def se_apply(self, dt, y, gate, residual, out, frames, Pn, Cc):
+        def step(stream):
+            n = frames * Pn * Cc
+            yr = y[:n].reshape(frames, Pn, Cc).to(self.acc)
+            o = yr * gate[: frames * Cc].reshape(frames, 1, Cc).to(self.acc)
+            if residual is not None:
+                o = o + residual[:n].reshape(frames, Pn, Cc).to(self.acc)
+            out[:n].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [o for o in [out] if o is not None]
+        step.what = 'se_apply'
+        return step
+
+    # ------------------------------------------------------------------ attention
+    def attention(self, dt, qkv, mem_kv, out, nseq, n, heads, dim_head, n_mem, causal, seq_inner, seq_outer_stride, tok_stride):
+        def step(stream):
+            ld = 3 * heads * dim_head
+            s = torch.arange(nseq)
+            base = (s // seq_inner) * seq_outer_stride + (s % seq_inner)
+            rows = base[:, None] + torch.arange(n)[None, :] * tok_stride                # (nseq, n)
+            nrows = int(rows.max()) + 1
+            Q = qkv[: nrows * ld].reshape(nrows, 3, heads, dim_head).to(self.acc)[rows]  # (nseq, n, 3, h, d)
+            q, k, v = Q[:, :, 0].transpose(1, 2), Q[:, :, 1].transpose(1, 2), Q[:, :, 2].transpose(1, 2)   # (nseq,h,n,d)
+            mk = mem_kv[0].to(self.acc).expand(nseq, -1, -1, -1)
+            mv = mem_kv[1].to(self.acc).expand(nseq, -1, -1, -1)
+            k = torch.cat((mk, k), dim=2); v = torch.cat((mv, v), dim=2)
+            dots = torch.einsum('shid,shjd->shij', q, k) * dim_head ** -0.5
+            if causal:
+                j = k.shape[2]
+                mask = torch.ones((n, j), dtype=torch.bool).triu(j - n + 1)
+                dots = dots.masked_fill(mask, float('-inf'))
+            o = torch.einsum('shij,shjd->shid', dots.softmax(dim=-1), v).transpose(1, 2).reshape(nseq, n, heads * dim_head)
+            ov = out[: nrows * heads * dim_head].reshape(nrows, heads * dim_head)
+            ov[rows.reshape(-1)] = o.reshape(-1, heads * dim_head).to(out.dtype)
+        step.outs = [o for o in [out] if o is not None]
+        step.what = 'attention'
+        return step
+
+    @staticmethod
+    def _phi(x):
+        x0 = x.new_ones(x.shape[:-1] + (1,))
+        x2 = (x.unsqueeze(-1) * x.unsqueeze(-2)).flatten(-2) * (0.5 ** 0.5)
+        return torch.cat((x0, x, x2), dim=-1)
+
+    def taylor_kv(self, dt, kv, part, frames, n, heads, nchunk):
+        def step(stream):
+            KV = kv[: frames * n * 2 * heads * 8].reshape(frames, n, 2, heads, 8).to(self.acc)
+            k, v = KV[:, :, 0], KV[:, :, 1]                                             # (f, n, h, 8)
+            v1 = torch.cat((v, v.new_ones(v.shape[:-1] + (1,))), dim=-1)
+            ph = self._phi(k)
+            per = -(-n // nchunk)
+            pv = part[: frames * nchunk * heads * 657].reshape(frames, nchunk, heads, 73, 9)
+            for j in range(nchunk):
+                lo, hi = j * per, min(n, (j + 1) * per)
+                if lo >= hi:
+                    pv[:, j] = 0
+                    continue
+                pv[:, j] = torch.einsum('fnhd,fnhe->fhde', ph[:, lo:hi], v1[:, lo:hi]).float()
+        step.outs = [o for o in [part] if o is not None]
+        step.what = 'taylor_kv'
+        return step
+
+    def taylor_apply(self, dt, q, part, out, kvsum, frames, n, heads, nchunk):
+        def step(stream):
+            S = part[: frames * nchunk * heads * 657].reshape(frames, nchunk, heads, 73, 9).to(self.acc).sum(dim=1)
+            kvsum[: frames * heads * 657].copy_(S.reshape(-1).float())
+            qq = q[: frames * n * heads * 8].reshape(frames, n, heads, 8).to(self.acc) * 8 ** -0.5
+            acc = torch.einsum('fnhd,fhde->fnhe', self._phi(qq), S)
+            o = acc[..., :8] * (1.0 / acc[..., 8:].clamp(min=1e-5))
+            out[: frames * n * heads * 8].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [o for o in [out, kvsum] if o is not None]
+        step.what = 'taylor_apply'
+        return step
+
+    # ------------------------------------------------------------------ quantizers
+    def lfq(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
+        def step(stream):
+            z = x[: rows * Cc].reshape(rows, Cc).to(self.acc) @ w_in.to(self.acc).t() + b_in.to(self.acc)
+            if clamp > 0:
+                z = (z / clamp).tanh() * clamp
+            pos = (z > 0).reshape(rows, ncb, cb_dim)
+            mask = (2 ** torch.arange(cb_dim - 1, -1, -1)).long()
+            ids[:rows].copy_((pos.long() * mask).sum(dim=-1))
+            if prequant is not None:
+                prequant[:rows].copy_(z.float())
+            code = torch.where(z > 0, scale, -scale).to(self.acc)
+            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            quantized[: rows * Cc].copy_(o.reshape(-1).to(quantized.dtype))
+        step.outs = [o for o in [quantized, ids, prequant] if o is not None]
+        step.what = 'lfq'
+        return step
+
+    def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):
+        def step(stream):
+            mask = (2 ** torch.arange(cb_dim - 1, -1, -1)).long()
+            bits = (ids[:rows].long().reshape(rows, ncb, 1) & mask) != 0
+            code = torch.where(bits, scale, -scale).to(self.acc).reshape(rows, ncb * cb_dim)
+            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            out[: rows * Cc].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [o for o in [out] if o is not None]
+        step.what = 'lfq_codes'
+        return step
+
+    def fsq(self, dt, x, w_in, b_in, w_out, b_out, consts, quantized, ids, prequant, rows, Cc, cb_dim, ncb):
+        def step(stream):
+            z = x[: rows * Cc].reshape(rows, Cc).to(self.acc) @ w_in.to(self.acc).t() + b_in.to(self.acc)
+            z = z.reshape(rows, ncb, cb_dim).float()
+            bounded = (z + consts['shift']).tanh() * consts['half_l'] - consts['offset']
+            r = bounded.round()
+            code = r / consts['half_w']
+            lvl = (code * consts['half_w'] + consts['half_w']) * consts['basis']
+            ids[:rows].copy_(lvl.sum(dim=-1).to(torch.int32))
+            if prequant is not None:
+                prequant[:rows].copy_(bounded.reshape(rows, -1))
+            o = code.reshape(rows, -1).to(self.acc) @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            quantized[: rows * Cc].copy_(o.reshape(-1).to(quantized.dtype))
+        step.outs = [o for o in [quantized, ids, prequant] if o is not None]
+        step.what = 'fsq'
+        return step
+
+    def fsq_codes(self, dt, ids, w_out, b_out, consts, out, rows, Cc, cb_dim, ncb):
+        def step(stream):
+            lv = (ids[:rows].reshape(rows, ncb, 1) // consts['basis']) % consts['levels']
+            code = ((lv - consts['half_w']) / consts['half_w']).reshape(rows, -1).to(self.acc)
+            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            out[: rows * Cc].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [o for o in [out] if o is not None]
+        step.what = 'fsq_codes'
+        return step

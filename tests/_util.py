@@ -1,0 +1,44 @@
+"""Shared helpers for the test-suite (golden fixtures, seeded weights / inputs)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
+from oracle.make_golden import make_input, sha_tensors, weights_sha
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'), allow_pickle=False)
+        self.name = name
+        self.kw = json.loads(str(z['cfg']))
+        if 'layers' in self.kw:
+            self.kw['layers'] = tuple(tuple(l) if isinstance(l, list) else l for l in self.kw['layers'])
+        self.cfg = make_cfg(**self.kw)
+        self.shape = tuple(int(v) for v in z['shape'])
+        self.weight_seed, self.data_seed, self.stride = int(z['weight_seed']), int(z['data_seed']), int(z['stride'])
+        self.codes = torch.from_numpy(z['codes'])
+        self.recon_sample = torch.from_numpy(z['recon_sample'])
+        self.recon_mean, self.recon_std, self.recon_abs_sum = float(z['recon_mean']), float(z['recon_std']), float(z['recon_abs_sum'])
+        self._wsha, self._isha = str(z['weights_sha256']), str(z['input_sha256'])
+
+    def weights(self):
+        sd = init_state_dict(self.cfg, seed=self.weight_seed, randomize_se=True)
+        assert weights_sha(sd) == self._wsha, 'seeded weights are not reproducible on this box (torch RNG drift?)'
+        return sd
+
+    def video(self):
+        v = make_input(self.shape, self.data_seed)
+        assert sha_tensors([v]) == self._isha, 'seeded input is not reproducible on this box'
+        return v
+
+    def sample(self, recon):
+        return recon[..., ::self.stride, ::self.stride]
+
+
+def live_cfg(**kw):
+    return make_cfg(**kw)

@@ -1,0 +1,57 @@
+"""Oracle pinning, part 2 (authoring container only): execute the reference's own code from
+/root/reference under the shim loader and require oracle/restate.py to agree on fresh seeds,
+and the product's weight contract (key names / shapes) to equal the reference's state_dict."""
+import pytest
+import torch
+
+from magvit2_pytorch_amd.spec import README_LAYERS, init_state_dict, make_cfg
+from oracle.ref_loader import make_reference_tokenizer, reference_available
+from oracle.restate import OracleTokenizer
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason='/root/reference only exists in the authoring container')
+
+KW = [
+    dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS),
+    dict(image_size=32, init_dim=8, max_dim=32, use_fsq=True, fsq_levels=[8, 5, 5, 5], layers=README_LAYERS),
+    dict(image_size=32, init_dim=8, max_dim=32, codebook_size=64, num_codebooks=2,
+         layers=('residual', 'compress_space', ('consecutive_residual', 2), 'attend_space', 'compress_time', 'attend_time')),
+]
+
+
+@pytest.mark.parametrize('kw', KW)
+def test_restatement_matches_reference(kw):
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=11, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    rsd = {k: v for k, v in ref.state_dict().items() if not k.startswith('discr.')}
+    assert set(rsd) == set(sd), set(rsd) ^ set(sd)
+    for k in sd:
+        assert tuple(rsd[k].shape) == tuple(sd[k].shape), k
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith('discr.') for m in missing)
+    v = torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes)
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    assert ocodes.dtype == codes.dtype and torch.equal(ocodes, codes)
+    assert torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
+
+
+def test_reference_default_init_families():
+    """our init draws from the same families as the reference's modules (spot checks)."""
+    kw = KW[0]
+    ref = make_reference_tokenizer(**kw)
+    rsd = ref.state_dict()
+    sd = init_state_dict(make_cfg(**kw), seed=0)
+    for k in ('encoder_layers.0.fn.4.net.2.weight', 'encoder_layers.0.fn.4.net.2.bias'):
+        assert torch.equal(rsd[k], sd[k])                          # zeros / -10 (reference :218-219)
+    k = 'decoder_layers.7.net.0.weight'                            # SpatialUpsample2x repeat-init (reference :829-836)
+    w = sd[k]
+    assert torch.equal(w[0::4], w[1::4]) and torch.equal(w[0::4], w[3::4])
+    rw = rsd[k]
+    assert torch.equal(rw[0::4], rw[1::4])
+    for k in ('conv_in.conv.weight', 'encoder_layers.2.0.fn.0.conv.weight'):
+        assert abs(rsd[k].abs().max().item() - sd[k].abs().max().item()) / rsd[k].abs().max().item() < 0.05
