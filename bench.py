@@ -34,6 +34,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(f'[bench +{time.perf_counter() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,11 +105,14 @@ def main():
     B, T = args.batch_per_gpu, args.frames
     video = torch.randn(B, 3, T, 128, 128, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
 
+    log(f'model + input ready on {dev} ({args.dtype}, B={B}, T={T})')
+
     def step():
         return tok(video, return_codes=True, return_recon=True)
 
     for _ in range(max(args.warmup, 3)):            # >= 3: eager run, graph capture, first replay
         step()
+    log('warm-up done (eager, graph capture, replay)')
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -125,10 +136,12 @@ def main():
         return
     frames_total = world * B * T * args.steps
     value = frames_total / el
+    log(f'timed region: {el / args.steps * 1e3:.3f} ms/step -> {value:.1f} frames/s')
 
     # ---- roofline of the dominant kernel (rank 0)
     ops = tok._backend()
     rows = per_launch_profile(tok, video, ops)
+    log('per-launch event profile done')
     conv = [r for r in rows if r['what'] == 'mv2_conv']
     conv_ms = sum(r['ms'] for r in conv)
     conv_flops = sum(r['flops'] for r in conv)
@@ -151,21 +164,33 @@ def main():
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
         from oracle.restate import OracleTokenizer
-        ncores = os.cpu_count() or 1
+        # cores this process may actually run on (a container's cpu_count() can overstate it wildly,
+        # and oversubscribed oneDNN threads make the baseline look absurdly slow)
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        ncores = max(1, min(ncores, int(os.environ.get('MV2_CPU_BASELINE_THREADS', '64'))))
         torch.set_num_threads(ncores)
+        log(f'cpu baseline: oracle on {ncores} threads (cpu_count={os.cpu_count()})')
         orc = OracleTokenizer(sd, **cfg)
         vc = video[:1].cpu()
-        orc(vc, return_codes=True, return_recon=True)                 # warm-up
-        ts = []
-        for _ in range(3):
+        t1 = time.perf_counter()
+        oc, orc_recon = orc(vc, return_codes=True, return_recon=True)                 # warm-up
+        ts = [time.perf_counter() - t1]
+        log(f'cpu baseline: warm-up {ts[0]:.2f} s')
+        budget = 30.0                                                              # bounded sample (seconds of CPU wall)
+        while len(ts) < 4 and sum(ts) + ts[-1] < budget:
             t1 = time.perf_counter()
             oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
             ts.append(time.perf_counter() - t1)
-        med = sorted(ts)[1]
+        timed = ts[1:] if len(ts) > 1 else ts
+        med = sorted(timed)[len(timed) // 2]
         mism = (codes[:1].cpu() != oc).float().mean().item()
         derr = (recon[:1].cpu() - orc_recon).abs().mean().item()
-        cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                            sample=f'1 clip (1,3,{T},128,128) fp32 x 3 timed runs after 1 warm-up, median {med:.2f} s/clip',
+        cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=ncores, kind='port',
+                            sample=f'1 clip (1,3,{T},128,128) fp32, {len(timed)} timed run(s) after warm-up, median {med:.2f} s/clip '
+                                   f'(bounded to ~{budget:.0f} s of CPU time)',
                             ids_mismatch_vs_gpu=round(mism, 5), recon_mean_abs_diff_vs_gpu=round(derr, 6))
 
     out = dict(

@@ -137,12 +137,13 @@ int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64_t rows, in
  * SqueezeExcite (M:221-240) in three stream-ordered launches over frames = B*T, P = H*W:
  *   pool : per frame chunk online-softmax partials of  softmax_p(wk.y_p + bk)  weighted channel sums
  *          part[(f*nchunk + j)*(C+2)] = {max, sumexp, psum[C]}
- *   gate : combines the partials, 1x1 MLP (LeakyReLU 0.1) and sigmoid -> gate[f][C] (fp32)
+ *   gate : combines the partials, 1x1 MLP (LeakyReLU 0.1) and sigmoid -> gate[f][C] (fp32);
+ *          the two weight matrices are passed TRANSPOSED: w1t (C, hidden), w2t (hidden, C)
  *   apply: out = gate[f] * y + residual            (also the Residual add of M:174)
  * ------------------------------------------------------------------------------------------- */
 int mv2_se_pool(int dtype, const void* y, const float* wk, float bk, float* part, int frames, int P, int C,
                 int nchunk, void* stream);
-int mv2_se_gate(const float* part, const float* w1, const float* b1, const float* w2, const float* b2,
+int mv2_se_gate(const float* part, const float* w1t, const float* b1, const float* w2t, const float* b2,
                 float* gate, int frames, int C, int hidden, int nchunk, void* stream);
 int mv2_se_apply(int dtype, const void* y, const float* gate, const void* residual, void* out, int frames,
                  int P, int C, void* stream);

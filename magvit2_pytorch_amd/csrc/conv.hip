@@ -11,113 +11,8 @@
 // Activation gathers go through a raw buffer descriptor: a tap that falls into the causal /
 // "same" zero padding is redirected to offset = num_records, for which the hardware returns 0,
 // so the halo costs no VALU selects and no branches.
-#include "common.h"
-
-struct ConvParams {
-    mv2_conv_desc d;
-    const void* in;
-    const void* wp;
-    const mv2_seg* segs;
-    const float* bias;
-    const float* rowscale;
-    const void* residual;
-    void* out;
-    float* ws;
-    uint32_t in_bytes;
-    uint32_t w_bytes;
-    int64_t M;
-    int32_t lg_seg_chunks;
-    int32_t n_co_tiles, n_pos_tiles;
-    int32_t steps_per_split, splitk;
-    int32_t ws_cols;
-    int64_t ws_rows;
-};
-
-// ------------------------------------------------------------------------------- epilogue
-template <typename E>
-__device__ __forceinline__ void decode_pos(const mv2_conv_desc& d, int64_t m, int& b, int& t, int& h, int& w) {
-    w = (int)(m % d.Wo); int64_t r = m / d.Wo;
-    h = (int)(r % d.Ho); r /= d.Ho;
-    t = (int)(r % d.To); b = (int)(r / d.To);
-}
-
-// v[4]: raw accumulators of 4 consecutive packed columns n..n+3 of position row m
-template <typename E>
-__device__ __forceinline__ void epi_store4(const ConvParams& p, int64_t m, int n, float* v) {
-    const mv2_conv_desc& d = p.d;
-    if (m >= p.M || n >= d.co) return;
-    if (p.rowscale) { float s = p.rowscale[m];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= s; }
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (n + j < d.co) v[j] += p.bias[n + j]; }
-    if (d.act == MV2_ACT_ELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_elu(v[j]);
-    } else if (d.act == MV2_ACT_SILU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_silu(v[j]);
-    }
-    if (d.store == MV2_STORE_ROWS) {
-        int64_t o = m * d.out_c + n;
-        if (p.residual) { float r[4]; ld4<E>(p.residual, o, r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j]; }
-        st4<E>(p.out, o, v);
-    } else if (d.store == MV2_STORE_SHUFFLE) {
-        int b, t, h, w; decode_pos<E>(d, m, b, t, h, w);
-        const int cq = d.out_c;
-        const int q = n / cq, c = n - q * cq;
-        const int qw = q % d.rw, qh = (q / d.rw) % d.rh, qt = q / (d.rw * d.rh);
-        const int64_t orow = (((int64_t)b * (d.To * d.rt) + (t * d.rt + qt)) * (d.Ho * d.rh) + (h * d.rh + qh)) * (d.Wo * d.rw) + (w * d.rw + qw);
-        st4<E>(p.out, orow * cq + c, v);
-    } else {   // MV2_STORE_NCTHW_F32
-        int b, t, h, w; decode_pos<E>(d, m, b, t, h, w);
-        const int to = t - d.crop_t;
-        if (to < 0) return;
-        const int64_t plane = (int64_t)d.Ho * d.Wo;
-        const int Tout = d.To - d.crop_t;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < d.co) ((float*)p.out)[(((int64_t)b * d.co + (n + j)) * Tout + to) * plane + (int64_t)h * d.Wo + w] = v[j];
-    }
-}
-
-// GEGLU: value columns nx..nx+3, gate columns nx+32.., output channels j0..j0+3
-template <typename E>
-__device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int nx, int j0, float* x, float* g) {
-    const mv2_conv_desc& d = p.d;
-    if (m >= p.M || nx >= d.co) return;
-    if (p.rowscale) { float s = p.rowscale[m];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { x[j] *= s; g[j] *= s; } }
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float xv = x[j], gv = g[j];
-        if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
-        o[j] = act_gelu(gv) * xv;
-    }
-    st4<E>(p.out, m * d.out_c + j0, o);
-}
-
-// ------------------------------------------------------------------------------- MFMA step
-template <typename E> struct Mma;
-template <> struct Mma<BF16> {
-    static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<F32> {
-    // 16 B = 4 fp32 per lane -> 4 x v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); the k order is
-    // a fixed permutation shared by both operands (lane half hi owns k = 4*hi + j of each 8-block).
-    static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a[j]), __int_as_float(b[j]), acc, 0, 0, 0);
-    }
-};
+#include <cstdlib>
+#include "conv_common.h"
 
 // ------------------------------------------------------------------------------- main kernel
 template <typename E, int BCO, int BPOS, int WCO, int WPOS>
@@ -354,7 +249,21 @@ struct Launch {
     int n_co_tiles, n_pos_tiles, splitk, steps_per_split;
     int64_t M, ws_rows;
     int ws_cols;
+    // halo-tiled variant (conv_halo.hip)
+    bool halo;
+    int th, tw, tiles_h, tiles_w, nchunk, chunks_per_split;
 };
+
+// stride-1 kt x 3 x 3 "same"/causal convolution over whole 128-byte channel chunks -> halo kernel
+inline bool halo_eligible(const mv2_conv_desc& d) {
+    static const bool off = getenv("MV2_NO_HALO") != nullptr;
+    if (off) return false;
+    const int es = d.dtype == MV2_BF16 ? 2 : 4;
+    return d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 &&
+           d.pt == d.kt - 1 && d.kt <= 3 && d.check_bounds && d.seg_bytes == 128 && (d.Ci * es) % 128 == 0 &&
+           d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) &&
+           d.act != MV2_ACT_GEGLU && d.co >= 64;
+}
 
 int g_cus = 0;
 inline int device_cus() {
@@ -380,8 +289,35 @@ inline int validate(const mv2_conv_desc& d) {
 
 inline Launch plan_launch(const mv2_conv_desc& d) {
     Launch L;
-    L.t = pick_tile(d);
+    L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
+    if (halo_eligible(d)) {
+        L.halo = true;
+        const int es = d.dtype == MV2_BF16 ? 2 : 4;
+        if (d.co <= 64) { L.t = {64, 256}; L.th = 16; L.tw = 16; }
+        else { L.t = {128, 128}; L.th = 8; L.tw = 16; }
+        L.tiles_h = (d.Ho + L.th - 1) / L.th;
+        L.tiles_w = (d.Wo + L.tw - 1) / L.tw;
+        L.nchunk = (d.Ci * es) / 128;
+        L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
+        L.n_pos_tiles = d.B * d.To * L.tiles_h * L.tiles_w;
+        int sk = d.splitk;
+        if (sk <= 0) {
+            sk = 1;
+            const int64_t blocks = (int64_t)L.n_co_tiles * L.n_pos_tiles;
+            const int cus = device_cus();
+            if (blocks < cus + cus / 2) sk = (int)((2 * cus + blocks - 1) / blocks);
+        }
+        if (sk > L.nchunk) sk = L.nchunk;
+        if (sk < 1) sk = 1;
+        L.chunks_per_split = (L.nchunk + sk - 1) / sk;
+        L.splitk = (L.nchunk + L.chunks_per_split - 1) / L.chunks_per_split;
+        L.steps_per_split = 0;
+        L.ws_rows = L.M;
+        L.ws_cols = L.n_co_tiles * L.t.bco;
+        return L;
+    }
+    L.t = pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
     int sk = d.splitk;
@@ -423,7 +359,8 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
-    if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
+    if (L.halo) rc = mv2_launch_halo(p, L.t.bco, L.th, L.tw, st);
+    else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
     else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2>(p, L, st);
     else rc = launch_cfg<E, 32, 256, 1, 2>(p, L, st);
     if (rc != MV2_OK) return rc;
@@ -467,6 +404,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
     p.steps_per_split = L.steps_per_split; p.splitk = L.splitk;
     p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
+    p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
     if (L.splitk > 1) {
         const size_t need = (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
         if (!workspace || workspace_bytes < need) return MV2_EWORKSPACE;

@@ -1,0 +1,116 @@
+// Shared pieces of the implicit-GEMM convolution kernels: launch parameters, the fused epilogue and
+// the MFMA step (bf16 32x32x16 / exact-fp32 32x32x2).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+    mv2_conv_desc d;
+    const void* in;
+    const void* wp;
+    const mv2_seg* segs;
+    const float* bias;
+    const float* rowscale;
+    const void* residual;
+    void* out;
+    float* ws;
+    uint32_t in_bytes;
+    uint32_t w_bytes;
+    int64_t M;
+    int32_t lg_seg_chunks;
+    int32_t n_co_tiles, n_pos_tiles;
+    int32_t steps_per_split, splitk;
+    int32_t ws_cols;
+    int64_t ws_rows;
+    // halo-tiled 3x3 variant (conv_halo.hip)
+    int32_t tiles_h, tiles_w, nchunk, chunks_per_split;
+};
+
+// conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice
+int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st);
+
+// ------------------------------------------------------------------------------- epilogue
+template <typename E>
+__device__ __forceinline__ void decode_pos(const mv2_conv_desc& d, int64_t m, int& b, int& t, int& h, int& w) {
+    w = (int)(m % d.Wo); int64_t r = m / d.Wo;
+    h = (int)(r % d.Ho); r /= d.Ho;
+    t = (int)(r % d.To); b = (int)(r / d.To);
+}
+
+// v[4]: raw accumulators of 4 consecutive packed columns n..n+3 of position row m
+template <typename E>
+__device__ __forceinline__ void epi_store4(const ConvParams& p, int64_t m, int n, float* v) {
+    const mv2_conv_desc& d = p.d;
+    if (m >= p.M || n >= d.co) return;
+    if (p.rowscale) { float s = p.rowscale[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= s; }
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < d.co) v[j] += p.bias[n + j]; }
+    if (d.act == MV2_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_elu(v[j]);
+    } else if (d.act == MV2_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_silu(v[j]);
+    }
+    if (d.store == MV2_STORE_ROWS) {
+        int64_t o = m * d.out_c + n;
+        if (p.residual) { float r[4]; ld4<E>(p.residual, o, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j]; }
+        st4<E>(p.out, o, v);
+    } else if (d.store == MV2_STORE_SHUFFLE) {
+        int b, t, h, w; decode_pos<E>(d, m, b, t, h, w);
+        const int cq = d.out_c;
+        const int q = n / cq, c = n - q * cq;
+        const int qw = q % d.rw, qh = (q / d.rw) % d.rh, qt = q / (d.rw * d.rh);
+        const int64_t orow = (((int64_t)b * (d.To * d.rt) + (t * d.rt + qt)) * (d.Ho * d.rh) + (h * d.rh + qh)) * (d.Wo * d.rw) + (w * d.rw + qw);
+        st4<E>(p.out, orow * cq + c, v);
+    } else {   // MV2_STORE_NCTHW_F32
+        int b, t, h, w; decode_pos<E>(d, m, b, t, h, w);
+        const int to = t - d.crop_t;
+        if (to < 0) return;
+        const int64_t plane = (int64_t)d.Ho * d.Wo;
+        const int Tout = d.To - d.crop_t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < d.co) ((float*)p.out)[(((int64_t)b * d.co + (n + j)) * Tout + to) * plane + (int64_t)h * d.Wo + w] = v[j];
+    }
+}
+
+// GEGLU: value columns nx..nx+3, gate columns nx+32.., output channels j0..j0+3
+template <typename E>
+__device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int nx, int j0, float* x, float* g) {
+    const mv2_conv_desc& d = p.d;
+    if (m >= p.M || nx >= d.co) return;
+    if (p.rowscale) { float s = p.rowscale[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] *= s; g[j] *= s; } }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float xv = x[j], gv = g[j];
+        if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
+        o[j] = act_gelu(gv) * xv;
+    }
+    st4<E>(p.out, m * d.out_c + j0, o);
+}
+
+// ------------------------------------------------------------------------------- MFMA step
+template <typename E> struct Mma;
+template <> struct Mma<BF16> {
+    static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<F32> {
+    // 16 B = 4 fp32 per lane -> 4 x v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); the k order is
+    // a fixed permutation shared by both operands (lane half hi owns k = 4*hi + j of each 8-block).
+    static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a[j]), __int_as_float(b[j]), acc, 0, 0, 0);
+    }
+};
+

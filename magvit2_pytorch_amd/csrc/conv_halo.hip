@@ -1,0 +1,264 @@
+// Halo-tiled implicit-GEMM kernel for the stride-1 kt x 3 x 3 causal convolutions (the ResidualUnit
+// conv: ~81 % of the path's FLOPs, reference magvit2_pytorch.py:937 / CausalConv3d :892-928).
+//
+// The generic kernel (conv.hip) gathers the activation tile once per tap: every input row is pulled
+// through the vector-memory path 27 times, and with a one-step prefetch the K loop runs at the
+// ~11 B/clk/CU latency-bound gather rate instead of the MFMA rate.  Here a block owns a TH x TW
+// rectangle of one output frame and stages the (TH+2) x (TW+2) input halo of one 128-byte channel
+// chunk of one input frame into LDS ONCE; the nine spatial taps of that frame are then just nine
+// row offsets into the same LDS image.  Global -> LDS activation traffic drops from 27x to
+// kt * (TH+2)(TW+2)/(TH*TW) ~ 4x; only the per-tap weight tile (BCO x 128 B, L2-resident) streams.
+//
+// Pipeline: weights are register-prefetched two taps ahead (two register sets, selected statically by
+// tap parity) into a double-buffered LDS tile; the next group's halo is fetched into registers at the
+// first tap of the current group (two taps of flight before any younger load is waited for) and
+// written over the single halo image at the group boundary.  Zero padding (causal time front, "same"
+// space) comes for free from out-of-range buffer offsets returning 0.  Epilogue / split-K are shared
+// with conv.hip.
+#include <type_traits>
+#include "conv_common.h"
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <typename E, int BCO, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+    constexpr int BPOS = TH * TW;
+    constexpr int WCO = 2, WPOS = 2;
+    constexpr int NWPOS = BPOS / (32 * WPOS);
+    static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
+    constexpr int HWD = TW + 2;                    // halo row pitch (positions)
+    constexpr int HR = (TH + 2) * HWD;             // halo rows
+    constexpr int NH = (HR + 31) / 32;             // halo rows staged per thread
+    constexpr int RW = BCO / 32;
+    constexpr int HALO_BYTES = ((HR * 128 + 255) / 256) * 256;
+    constexpr int WBUF = BCO * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wlds = smem + HALO_BYTES;
+
+    const mv2_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int T = d.Ti, H = d.Hi, W = d.Wi;
+
+    int bid = blockIdx.x;
+    {
+        const int nblk = p.n_co_tiles * p.n_pos_tiles;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int co_tile = bid % p.n_co_tiles;
+    int pt_ = bid / p.n_co_tiles;
+    const int twi = pt_ % p.tiles_w; pt_ /= p.tiles_w;
+    const int thi = pt_ % p.tiles_h; pt_ /= p.tiles_h;
+    const int t = pt_ % T; const int b = pt_ / T;
+    const int h0 = thi * TH, w0 = twi * TW;
+    const int n0 = co_tile * BCO;
+    const int z = blockIdx.y;
+    const int c_begin = z * p.chunks_per_split;
+    const int c_end = min(p.nchunk, c_begin + p.chunks_per_split);
+    const int kt = d.kt;
+    const int G = (c_end - c_begin) * kt;           // halo groups: (chunk, it)
+    const int S = G * 9;                            // taps
+
+    // ---- halo gather state: validity bits are held, offsets are recomputed where used (VGPR budget)
+    uint32_t hmask = 0;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hr = r0 + 32 * i;
+        if (hr < HR) {
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
+            if ((unsigned)hin < (unsigned)H && (unsigned)win < (unsigned)W) hmask |= 1u << i;
+        }
+    }
+    const uint32_t row_bytes = (uint32_t)d.Ci * E::kBytes;
+    const uint32_t hw_base = (uint32_t)(((int64_t)(h0 - 1) * W + (w0 - 1)) * (int64_t)row_bytes);
+    const uint32_t frame_bytes = (uint32_t)((int64_t)H * W * d.Ci * E::kBytes);
+    const uint32_t w_off0 = (uint32_t)(n0 + r0) * 128u + (uint32_t)c * 16u;
+    const uint32_t w_step = (uint32_t)d.co_pad * 128u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.w_bytes, 0x00020000);
+
+    const uint32_t lds_wr = (uint32_t)r0 * 128u + (uint32_t)((c ^ ((r0 >> 1) & 7)) << 4);
+    const int wco = wave / NWPOS, wpos = wave % NWPOS;
+    const uint32_t swz = (uint32_t)((l31 >> 1) & 7);
+    const uint32_t rd_w = (uint32_t)(wco * 32 * WCO + l31) * 128u;
+    // this lane's two positions inside the tile -> halo row of their (dh = -1, dw = -1) tap
+    int prow0[WPOS];
+#pragma unroll
+    for (int bb = 0; bb < WPOS; ++bb) {
+        const int pp = wpos * 32 * WPOS + bb * 32 + l31;
+        prow0[bb] = (pp / TW) * HWD + (pp % TW);
+    }
+
+    f32x16 acc[WCO][WPOS];
+#pragma unroll
+    for (int a = 0; a < WCO; ++a)
+#pragma unroll
+        for (int bb = 0; bb < WPOS; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
+
+    i32x4 hreg[NH];
+    i32x4 wreg[2][RW];
+
+    auto issue_halo = [&](int g) {
+        const int chunk = c_begin + g / kt, it = g % kt;
+        const int t_in = t + it - d.pt;
+        const bool tok = t_in >= 0 && t_in < T;
+        const uint32_t base = (uint32_t)(((int64_t)b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + hw_base;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hr = r0 + 32 * i;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const bool ok = tok && ((hmask >> i) & 1u);
+            const uint32_t vo = ok ? base + (uint32_t)(hy * W + hx) * row_bytes : p.in_bytes;
+            hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
+        }
+    };
+    auto write_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (r0 + 32 * i < HR) *(i32x4*)(halo + lds_wr + i * 32 * 128) = hreg[i];
+    };
+    auto w_offset = [&](int s) {            // byte offset of this thread's first weight chunk of tap s
+        const int g = s / 9, tp = s - g * 9;
+        const int chunk = c_begin + g / kt, it = g % kt;
+        return w_off0 + (uint32_t)((it * 9 + tp) * p.nchunk + chunk) * w_step;
+    };
+
+    if (S > 0) {
+        // prologue: halo of group 0, weights of taps 0 and 1
+        issue_halo(0);
+        {
+            const uint32_t wo_ = w_offset(0);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) wreg[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
+        }
+        if (S > 1) {
+            const uint32_t wo_ = w_offset(1);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) wreg[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
+        }
+        write_halo();
+#pragma unroll
+        for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * 32 * 128) = wreg[0][i];
+        __syncthreads();
+
+        // one tap.  PAR = s & 1 is compile-time (register set / LDS weight buffer).  W(s+2) is issued into
+        // wreg[PAR] (free: W(s) went to LDS during tap s-1); W(s+1), issued one tap ago into wreg[PAR^1], is
+        // written to LDS buffer PAR^1 after this tap's MFMAs.
+        auto tap = [&](int s, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int g = s / 9, tp = s - g * 9;
+            if (s + 2 < S) {
+                const uint32_t wo_ = w_offset(s + 2);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) wreg[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
+            }
+            if (tp == 0 && g + 1 < G) issue_halo(g + 1);
+            const char* wb = wlds + PAR * WBUF;
+            const int t3 = tp / 3;
+            const int toff = t3 * HWD + (tp - 3 * t3);
+            uint32_t pbase[WPOS], psw[WPOS];
+#pragma unroll
+            for (int bb = 0; bb < WPOS; ++bb) {
+                const int pr = prow0[bb] + toff;
+                pbase[bb] = (uint32_t)pr * 128u;
+                psw[bb] = (uint32_t)((pr >> 1) & 7);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint32_t ck = (uint32_t)(ks * 2 + hi);
+                i32x4 fw[WCO], fp[WPOS];
+#pragma unroll
+                for (int a = 0; a < WCO; ++a) fw[a] = *(const i32x4*)(wb + rd_w + a * 32 * 128 + ((ck ^ swz) << 4));
+#pragma unroll
+                for (int bb = 0; bb < WPOS; ++bb) fp[bb] = *(const i32x4*)(halo + pbase[bb] + ((ck ^ psw[bb]) << 4));
+#pragma unroll
+                for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
+            }
+            if (s + 1 < S) {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
+            }
+            if (tp == 8 && g + 1 < G) {
+                __syncthreads();          // every wave is done with halo image g
+                write_halo();
+            }
+            __syncthreads();
+        };
+        int s = 0;
+        for (; s + 1 < S; s += 2) {
+            tap(s, IC<0>{});
+            tap(s + 1, IC<1>{});
+        }
+        if (s < S) tap(s, IC<0>{});
+    }
+
+    // ---- epilogue (shared with conv.hip)
+    const int nbase = n0 + wco * 32 * WCO;
+    int64_t mrow[WPOS];
+#pragma unroll
+    for (int bb = 0; bb < WPOS; ++bb) {
+        const int pp = wpos * 32 * WPOS + bb * 32 + l31;
+        const int ph = pp / TW, pw = pp % TW;
+        const bool ok = (h0 + ph) < H && (w0 + pw) < W;
+        mrow[bb] = ok ? ((((int64_t)b * T + t) * H + (h0 + ph)) * W + (w0 + pw)) : p.M;
+    }
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int a = 0; a < WCO; ++a)
+#pragma unroll
+            for (int bb = 0; bb < WPOS; ++bb) {
+                if (mrow[bb] >= p.M) continue;
+                float* row = p.ws + ((int64_t)z * p.ws_rows + mrow[bb]) * p.ws_cols + nbase + a * 32 + 4 * hi;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[a][bb][4 * g], acc[a][bb][4 * g + 1], acc[a][bb][4 * g + 2], acc[a][bb][4 * g + 3]};
+                    *(f32x4*)(row + 8 * g) = v;
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < WCO; ++a)
+#pragma unroll
+        for (int bb = 0; bb < WPOS; ++bb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[a][bb][4 * g + j];
+                epi_store4<E>(p, mrow[bb], nbase + a * 32 + 8 * g + 4 * hi, v);
+            }
+        }
+}
+
+template <typename E, int BCO, int TH, int TW>
+static int launch_one(const ConvParams& p, hipStream_t st) {
+    constexpr int HR = (TH + 2) * (TW + 2);
+    constexpr size_t lds = (size_t)((HR * 128 + 255) / 256) * 256 + 2 * (size_t)BCO * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW>), grid, dim3(256), lds, st, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st) {
+    const bool bf = p.d.dtype == MV2_BF16;
+    if (bco == 64 && th == 16 && tw == 16) return bf ? launch_one<BF16, 64, 16, 16>(p, st) : launch_one<F32, 64, 16, 16>(p, st);
+    if (bco == 128 && th == 8 && tw == 16) return bf ? launch_one<BF16, 128, 8, 16>(p, st) : launch_one<F32, 128, 8, 16>(p, st);
+    return MV2_EINVAL;
+}

@@ -48,9 +48,10 @@ class PackedModel:
             c = sd[pre + '.fn.2.weight'].shape[0]
             self.f32[pre + '.se.wk'] = dev(f(pre + '.fn.4.to_k.weight').reshape(c).contiguous())
             self.f32[pre + '.se.bk'] = f(pre + '.fn.4.to_k.bias').reshape(())          # host scalar
-            self.f32[pre + '.se.w1'] = dev(f(pre + '.fn.4.net.0.weight').flatten(1).contiguous())
+            # transposed for coalesced thread-per-output reads: w1t (C, hidden), w2t (hidden, C)
+            self.f32[pre + '.se.w1'] = dev(f(pre + '.fn.4.net.0.weight').flatten(1).t().contiguous())
             self.f32[pre + '.se.b1'] = dev(f(pre + '.fn.4.net.0.bias'))
-            self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).contiguous())
+            self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous())
             self.f32[pre + '.se.b2'] = dev(f(pre + '.fn.4.net.2.bias'))
 
         def feed_forward(pre, dim, token_shift):

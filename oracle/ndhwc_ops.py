@@ -198,8 +198,9 @@ class CpuOps:
             w = (pv[:, :, 0] - M[:, None]).exp()
             S = (pv[:, :, 1] * w).sum(dim=1)
             pooled = (pv[:, :, 2:] * w[:, :, None]).sum(dim=1) / S[:, None]
-            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc).t() + b1.to(self.acc), 0.1)
-            g = torch.sigmoid(h @ w2.to(self.acc).t() + b2.to(self.acc))
+            # w1 / w2 arrive transposed (include/mv2.h): w1t (C, hidden), w2t (hidden, C)
+            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc) + b1.to(self.acc), 0.1)
+            g = torch.sigmoid(h @ w2.to(self.acc) + b2.to(self.acc))
             gate[: frames * Cc].copy_(g.reshape(-1).float())
         step.outs = [o for o in [gate] if o is not None]
         step.what = 'se_gate'
