@@ -92,42 +92,48 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    i32x4 gw[RW], gp[RP];
+    // Two register sets (selected statically by step parity): the loads of step s+2 are issued while
+    // step s computes and step s+1 (issued one step earlier) is written to the other LDS buffer, so every
+    // gather has two steps of flight time before it is waited for.
+    i32x4 gw[2][RW], gp[2][RP];
 
     auto load_seg = [&](int s) { return p.segs[s * segs_per_step + seg_sub]; };
-    auto issue_loads = [&](int s, const mv2_seg sg) {
+    auto issue_loads = [&](int s, const mv2_seg sg, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
         const uint32_t so = (uint32_t)sg.elem_offset * (uint32_t)E::kBytes + seg_inner;
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             const bool ok = (rowmask[i] & sg.sel) == sg.sel;
             const uint32_t vo = ok ? rowbase[i] + so : p.in_bytes;
-            gp[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
+            gp[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
         const uint32_t wo_ = w_off0 + (uint32_t)s * w_step;
 #pragma unroll
         for (int i = 0; i < RW; ++i)
-            gw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 32u * 128u), 0, 0);
+            gw[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 32u * 128u), 0, 0);
     };
-    auto write_lds = [&](int buf) {
-        char* base = smem + buf * STAGE;
+    auto write_lds = [&](auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        char* base = smem + PAR * STAGE;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) *(i32x4*)(base + lds_wr + i * 32 * 128) = gw[i];
+        for (int i = 0; i < RW; ++i) *(i32x4*)(base + lds_wr + i * 32 * 128) = gw[PAR][i];
 #pragma unroll
-        for (int i = 0; i < RP; ++i) *(i32x4*)(base + BCO * 128 + lds_wr + i * 32 * 128) = gp[i];
+        for (int i = 0; i < RP; ++i) *(i32x4*)(base + BCO * 128 + lds_wr + i * 32 * 128) = gp[PAR][i];
     };
 
     if (s_begin < s_end) {
+        // parity is relative to s_begin: step s_begin uses set / buffer 0
         mv2_seg sg = load_seg(s_begin);
-        issue_loads(s_begin, sg);
-        if (s_begin + 1 < s_end) sg = load_seg(s_begin + 1);   // segment descriptors run one step ahead
-        write_lds(0);
+        issue_loads(s_begin, sg, IC<0>{});
+        if (s_begin + 1 < s_end) { sg = load_seg(s_begin + 1); issue_loads(s_begin + 1, sg, IC<1>{}); }
+        if (s_begin + 2 < s_end) sg = load_seg(s_begin + 2);    // descriptors run ahead of their loads
+        write_lds(IC<0>{});
         __syncthreads();
-        int buf = 0;
-        for (int s = s_begin; s < s_end; ++s) {
-            const bool more = (s + 1) < s_end;
-            if (more) issue_loads(s + 1, sg);
-            if (s + 2 < s_end) sg = load_seg(s + 2);
-            const char* base = smem + buf * STAGE;
+        auto step = [&](int s, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
+            if (s + 2 < s_end) issue_loads(s + 2, sg, IC<PAR>{});
+            if (s + 3 < s_end) sg = load_seg(s + 3);
+            const char* base = smem + PAR * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const uint32_t ck = (uint32_t)(((ks * 2 + hi) ^ swz) << 4);
@@ -141,10 +147,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[a], fp[b], acc[a][b]);
             }
-            if (more) write_lds(buf ^ 1);
+            if (s + 1 < s_end) write_lds(IC<PAR ^ 1>{});
             __syncthreads();
-            buf ^= 1;
+        };
+        int s = s_begin;
+        for (; s + 1 < s_end; s += 2) {
+            step(s, IC<0>{});
+            step(s + 1, IC<1>{});
         }
+        if (s < s_end) step(s, IC<0>{});
     }
 
     // ---- epilogue: acc[a][b][r] is D[co = 8*(r>>2) + 4*hi + (r&3)][pos = l31] of tile (a, b)
@@ -405,6 +416,10 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.steps_per_split = L.steps_per_split; p.splitk = L.splitk;
     p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
     p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
+    {
+        static const int ab = getenv("MV2_ABLATE") ? atoi(getenv("MV2_ABLATE")) : 0;   // timing experiments only: results are wrong
+        p.ablate = ab;
+    }
     if (L.splitk > 1) {
         const size_t need = (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
         if (!workspace || workspace_bytes < need) return MV2_EWORKSPACE;

@@ -1,7 +1,11 @@
 // Shared pieces of the implicit-GEMM convolution kernels: launch parameters, the fused epilogue and
 // the MFMA step (bf16 32x32x16 / exact-fp32 32x32x2).
 #pragma once
+#include <type_traits>
 #include "common.h"
+
+// compile-time int tag: lets a lambda body select a register set / LDS buffer statically
+template <int V> using IC = std::integral_constant<int, V>;
 
 struct ConvParams {
     mv2_conv_desc d;
@@ -23,6 +27,7 @@ struct ConvParams {
     int64_t ws_rows;
     // halo-tiled 3x3 variant (conv_halo.hip)
     int32_t tiles_h, tiles_w, nchunk, chunks_per_split;
+    int32_t ablate;   // profiling aid (env MV2_ABLATE): 1 no halo refetch, 2 no weight refetch, 4 no MFMA, 8 no epilogue
 };
 
 // conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice

@@ -15,10 +15,7 @@
 // written over the single halo image at the group boundary.  Zero padding (causal time front, "same"
 // space) comes for free from out-of-range buffer offsets returning 0.  Epilogue / split-K are shared
 // with conv.hip.
-#include <type_traits>
 #include "conv_common.h"
-
-template <int V> using IC = std::integral_constant<int, V>;
 
 template <typename E, int BCO, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
@@ -59,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     const int c_begin = z * p.chunks_per_split;
     const int c_end = min(p.nchunk, c_begin + p.chunks_per_split);
     const int kt = d.kt;
+    const int ab = p.ablate;
     const int G = (c_end - c_begin) * kt;           // halo groups: (chunk, it)
     const int S = G * 9;                            // taps
 
@@ -153,12 +151,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         auto tap = [&](int s, auto par_c) {
             constexpr int PAR = decltype(par_c)::value;
             const int g = s / 9, tp = s - g * 9;
-            if (s + 2 < S) {
+            if (s + 2 < S && !(ab & 2)) {
                 const uint32_t wo_ = w_offset(s + 2);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) wreg[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
             }
-            if (tp == 0 && g + 1 < G) issue_halo(g + 1);
+            if (tp == 0 && g + 1 < G && !(ab & 1)) issue_halo(g + 1);
             const char* wb = wlds + PAR * WBUF;
             const int t3 = tp / 3;
             const int toff = t3 * HWD + (tp - 3 * t3);
@@ -180,13 +178,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
+                    for (int bb = 0; bb < WPOS; ++bb) if (!(ab & 4)) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
             }
             if (s + 1 < S) {
 #pragma unroll
                 for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
             }
-            if (tp == 8 && g + 1 < G) {
+            if (tp == 8 && g + 1 < G && !(ab & 1)) {
                 __syncthreads();          // every wave is done with halo image g
                 write_halo();
             }
@@ -201,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     }
 
     // ---- epilogue (shared with conv.hip)
+    if (ab & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }
     const int nbase = n0 + wco * 32 * WCO;
     int64_t mrow[WPOS];
 #pragma unroll

@@ -192,78 +192,118 @@ extern "C" int mv2_se_pool(int dtype, const void* y, const float* wk, float bk, 
 }
 
 // --------------------------------------------------------------------------- SqueezeExcite: gate
-// one block per frame: merge chunk partials -> pooled[C]; hidden = lrelu(W1 pooled + b1);
-// gate = sigmoid(W2 hidden + b2).  Weights arrive TRANSPOSED (w1t[C][hidden], w2t[hidden][C]) so that
-// one thread per output unit reads them coalesced; the reduction operand is broadcast from LDS.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, const float* __restrict__ w1t,
-                                                      const float* __restrict__ b1, const float* __restrict__ w2t,
-                                                      const float* __restrict__ b2, float* __restrict__ gate, int C,
-                                                      int hidden, int nchunk) {
+// one 1024-thread block per frame: merge chunk partials -> pooled[C]; hidden = lrelu(W1 pooled + b1);
+// gate = sigmoid(W2 hidden + b2).  The work is tiny but latency-bound, so every reduction is split
+// over thread slices (output unit x reduction slice) and combined through LDS.  Weights arrive
+// TRANSPOSED (w1t[C][hidden], w2t[hidden][C]): lanes of a slice read consecutive output units.
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ part, const float* __restrict__ w1t,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                       int hidden, int nchunk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* pooled = sm;               // C
-    float* hid = sm + C;              // hidden
+    float* hid = pooled + C;          // hidden
     float* wj = hid + hidden;         // nchunk: exp(m_j - M)
-    float* red = wj + nchunk;         // 8 scratch
+    float* red = wj + nchunk;         // 32 scratch
+    float* slab = red + 32;           // 1024 partial sums
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pf = part + (int64_t)f * nchunk * (C + 2);
     float m = -INFINITY;
-    for (int j = tid; j < nchunk; j += 256) m = fmaxf(m, pf[(int64_t)j * (C + 2)]);
+    for (int j = tid; j < nchunk; j += 1024) m = fmaxf(m, pf[(int64_t)j * (C + 2)]);
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, red[w]);
     float s = 0.f;
-    for (int j = tid; j < nchunk; j += 256) {
+    for (int j = tid; j < nchunk; j += 1024) {
         const float mj = pf[(int64_t)j * (C + 2)];
         const float w = (mj == -INFINITY) ? 0.f : expf(mj - M);
         wj[j] = w;
         s += pf[(int64_t)j * (C + 2) + 1] * w;
     }
     s = wave_sum(s);
-    if (lane == 0) red[4 + wave] = s;
+    if (lane == 0) red[16 + wave] = s;
     __syncthreads();
-    const float inv_s = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int c = tid; c < C; c += 256) {
-        float a = 0.f;
-        for (int j = 0; j < nchunk; ++j) a += pf[(int64_t)j * (C + 2) + 2 + c] * wj[j];
-        pooled[c] = a * inv_s;
-    }
-    __syncthreads();
-    for (int k = tid; k < hidden; k += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int c = 0;
-        for (; c + 4 <= C; c += 4) {
-            a0 += w1t[(int64_t)(c + 0) * hidden + k] * pooled[c + 0];
-            a1 += w1t[(int64_t)(c + 1) * hidden + k] * pooled[c + 1];
-            a2 += w1t[(int64_t)(c + 2) * hidden + k] * pooled[c + 2];
-            a3 += w1t[(int64_t)(c + 3) * hidden + k] * pooled[c + 3];
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) S += red[16 + w];
+    const float inv_s = 1.f / S;
+    {   // pooled[c]: threads (c, j-slice)
+        const int JS = max(1, 1024 / C);
+        const int c = tid % C, js = tid / C;
+        if (js < JS) {
+            float a = 0.f;
+            for (int j = js; j < nchunk; j += JS) a += pf[(int64_t)j * (C + 2) + 2 + c] * wj[j];
+            slab[js * C + c] = a;
         }
-        for (; c < C; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
-        const float a = (a0 + a1) + (a2 + a3) + b1[k];
-        hid[k] = a > 0.f ? a : 0.1f * a;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= hidden; k += 4) {
-            a0 += w2t[(int64_t)(k + 0) * C + c] * hid[k + 0];
-            a1 += w2t[(int64_t)(k + 1) * C + c] * hid[k + 1];
-            a2 += w2t[(int64_t)(k + 2) * C + c] * hid[k + 2];
-            a3 += w2t[(int64_t)(k + 3) * C + c] * hid[k + 3];
+        __syncthreads();
+        if (tid < C) {
+            float a = 0.f;
+            for (int q = 0; q < JS; ++q) a += slab[q * C + tid];
+            pooled[tid] = a * inv_s;
         }
-        for (; k < hidden; ++k) a0 += w2t[(int64_t)k * C + c] * hid[k];
-        const float a = (a0 + a1) + (a2 + a3) + b2[c];
-        gate[(int64_t)f * C + c] = 1.f / (1.f + expf(-a));
+        __syncthreads();
+    }
+    {   // hidden[k]: threads (k, c-slice)
+        const int KS = max(1, 1024 / hidden);
+        const int k = tid % hidden, cs = tid / hidden;
+        const int per = (C + KS - 1) / KS;
+        if (cs < KS) {
+            const int c0 = cs * per, c1 = min(C, c0 + per);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int c = c0;
+            for (; c + 4 <= c1; c += 4) {
+                a0 += w1t[(int64_t)(c + 0) * hidden + k] * pooled[c + 0];
+                a1 += w1t[(int64_t)(c + 1) * hidden + k] * pooled[c + 1];
+                a2 += w1t[(int64_t)(c + 2) * hidden + k] * pooled[c + 2];
+                a3 += w1t[(int64_t)(c + 3) * hidden + k] * pooled[c + 3];
+            }
+            for (; c < c1; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
+            slab[cs * hidden + k] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (tid < hidden) {
+            float a = b1[tid];
+            for (int q = 0; q < KS; ++q) a += slab[q * hidden + tid];
+            hid[tid] = a > 0.f ? a : 0.1f * a;
+        }
+        __syncthreads();
+    }
+    {   // gate[c]: threads (c, k-slice)
+        const int GS = max(1, 1024 / C);
+        const int c = tid % C, ks = tid / C;
+        const int per = (hidden + GS - 1) / GS;
+        if (ks < GS) {
+            const int k0 = ks * per, k1 = min(hidden, k0 + per);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = k0;
+            for (; k + 4 <= k1; k += 4) {
+                a0 += w2t[(int64_t)(k + 0) * C + c] * hid[k + 0];
+                a1 += w2t[(int64_t)(k + 1) * C + c] * hid[k + 1];
+                a2 += w2t[(int64_t)(k + 2) * C + c] * hid[k + 2];
+                a3 += w2t[(int64_t)(k + 3) * C + c] * hid[k + 3];
+            }
+            for (; k < k1; ++k) a0 += w2t[(int64_t)k * C + c] * hid[k];
+            slab[ks * C + c] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (tid < C) {
+            float a = b2[tid];
+            for (int q = 0; q < GS; ++q) a += slab[q * C + tid];
+            gate[(int64_t)f * C + tid] = 1.f / (1.f + expf(-a));
+        }
     }
 }
 
 extern "C" int mv2_se_gate(const float* part, const float* w1t, const float* b1, const float* w2t, const float* b2,
                            float* gate, int frames, int C, int hidden, int nchunk, void* stream) {
     if (!part || !w1t || !b1 || !w2t || !b2 || !gate || frames <= 0 || nchunk <= 0) return MV2_EINVAL;
-    const size_t lds = (size_t)(C + hidden + nchunk + 8) * sizeof(float);
+    if (C <= 0 || C > 1024 || hidden <= 0 || hidden > 1024) return MV2_EINVAL;
+    const size_t lds = (size_t)(C + hidden + nchunk + 32 + 1024) * sizeof(float);
     if (lds > 64 * 1024) return MV2_EINVAL;
-    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)frames), dim3(256), lds, (hipStream_t)stream, part, w1t, b1, w2t, b2, gate, C, hidden, nchunk);
+    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)frames), dim3(1024), lds, (hipStream_t)stream, part, w1t, b1, w2t, b2, gate, C, hidden, nchunk);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }

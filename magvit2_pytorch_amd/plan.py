@@ -252,7 +252,7 @@ class Plan:
         y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
         self.arena.put(y1.t)
         frames, Pn, C = x.B * x.T, x.H * x.W, x.C
-        nchunk = max(1, min(Pn // 64 if Pn >= 64 else 1, -(-1024 // frames)))
+        nchunk = max(1, min(Pn // 16 if Pn >= 16 else 1, -(-1024 // frames)))   # ~1024 blocks, >= 16 rows per chunk
         part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
         gate = self.arena.get(frames * C, torch.float32)
         steps.append(ops.se_pool(self.dt, y2.t, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']), part, frames, Pn, C, nchunk))
