@@ -176,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             }
         return;
     }
+    if (stage_ok(p)) {   // LDS-staged, fully coalesced stores (the K loop ended on a barrier: LDS is free)
+        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; });
+        return;
+    }
     if (d.act == MV2_ACT_GEGLU) {
         if constexpr (WCO == 2) {
 #pragma unroll
@@ -353,7 +357,9 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
 
 template <typename E, int BCO, int BPOS, int WCO, int WPOS>
 int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)(BCO + BPOS) * 128;
+    constexpr size_t lds_main = 2 * (size_t)(BCO + BPOS) * 128;
+    constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, BPOS>::kBytes;
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_kernel<E, BCO, BPOS, WCO, WPOS>,

@@ -102,6 +102,121 @@ __device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int n
     st4<E>(p.out, m * d.out_c + j0, o);
 }
 
+// ------------------------------------------------------------------------------- LDS-staged epilogue
+// The MFMA accumulator layout gives each lane 4 consecutive channels of ONE position, 32 positions per
+// half-wave: a direct store touches 32 rows per instruction with 8 B each and is store-issue bound
+// (measured: ~47 % of the 3x3 kernel at C = 64).  Instead every wave finishes its values in registers
+// (rowscale, bias, activation, residual), drops them into a [position][channel] LDS tile, and the
+// block then streams the tile out with 16-byte-per-lane stores over whole rows.
+//   row_of(local_pos) -> global row m (>= p.M when the position is outside the tensor)
+template <typename E, int BCO, int BPOS>
+struct StageCfg {
+    static constexpr int kPitch = BCO * E::kBytes + 16;            // bytes per staged row (pad: bank spread)
+    static constexpr int kBytes = BPOS * kPitch;
+};
+
+template <typename E> __device__ __forceinline__ void lds_put4(char* dst, const float* v);
+template <> __device__ __forceinline__ void lds_put4<BF16>(char* dst, const float* v) {
+    i32x2 w;
+    w[0] = (int)((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16));
+    w[1] = (int)((unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+    *(i32x2*)dst = w;
+}
+template <> __device__ __forceinline__ void lds_put4<F32>(char* dst, const float* v) {
+    f32x4 w = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)dst = w;
+}
+
+__device__ __forceinline__ bool stage_ok(const ConvParams& p) {
+    const int es = p.d.dtype == MV2_BF16 ? 2 : 4;
+    return p.d.store != MV2_STORE_NCTHW_F32 && ((p.d.out_c * es) % 16) == 0 && (p.d.co % (16 / es)) == 0;
+}
+
+template <typename E, int BCO, int BPOS, int WCO, int WPOS, typename RowFn>
+__device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
+                                                int wpos, int tid, RowFn row_of) {
+    const mv2_conv_desc& d = p.d;
+    constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const bool geglu = d.act == MV2_ACT_GEGLU;
+    // ---- phase 1: finish values per lane, write the tile
+#pragma unroll
+    for (int b = 0; b < WPOS; ++b) {
+        const int lp = wpos * 32 * WPOS + b * 32 + l31;
+        const int64_t m = row_of(lp);
+        const bool valid = m < p.M;
+        const float rs = (valid && p.rowscale) ? p.rowscale[m] : 1.f;
+        char* rowp = lds + lp * PITCH;
+        if (geglu) {
+            if constexpr (WCO == 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int off = 8 * g + 4 * hi;
+                    const int nx = n0 + wco * 64 + off;          // packed value column; gate = +32
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float xv = acc[0][b][4 * g + j] * rs, gv = acc[1][b][4 * g + j] * rs;
+                        if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
+                        o[j] = act_gelu(gv) * xv;
+                    }
+                    lds_put4<E>(rowp + (wco * 32 + off) * E::kBytes, o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wco * 32 * WCO + a * 32 + 8 * g + 4 * hi;
+                    const int n = n0 + col;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[a][b][4 * g + j] * rs;
+                        if (p.bias) x += p.bias[n + j];
+                        if (d.act == MV2_ACT_ELU) x = act_elu(x);
+                        else if (d.act == MV2_ACT_SILU) x = act_silu(x);
+                        v[j] = x;
+                    }
+                    if (p.residual && valid && n < d.co) {
+                        float r[4]; ld4<E>(p.residual, m * d.out_c + n, r);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += r[j];
+                    }
+                    lds_put4<E>(rowp + col * E::kBytes, v);
+                }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: coalesced 16-byte stores of whole rows
+    const int width = geglu ? BCO / 2 : BCO;                      // staged channels per row
+    const int nbase = geglu ? n0 / 2 : n0;
+    const int nvalid = geglu ? d.out_c : d.co;                    // valid output columns
+    const int cpr = width * E::kBytes / 16;
+    const int total = BPOS * cpr;
+    for (int q = tid; q < total; q += 256) {
+        const int lp = q / cpr, ch = q - lp * cpr;
+        const int n = nbase + ch * E::kVec;
+        if (n >= nvalid) continue;
+        const int64_t m = row_of(lp);
+        if (m >= p.M) continue;
+        const i32x4 val = *(const i32x4*)(lds + lp * PITCH + ch * 16);
+        int64_t dst;
+        if (d.store == MV2_STORE_SHUFFLE) {
+            int b_, t_, h_, w_; decode_pos<E>(d, m, b_, t_, h_, w_);
+            const int cq = d.out_c;
+            const int qq = n / cq, c = n - qq * cq;
+            const int qw = qq % d.rw, qh = (qq / d.rw) % d.rh, qt = qq / (d.rw * d.rh);
+            const int64_t orow = (((int64_t)b_ * (d.To * d.rt) + (t_ * d.rt + qt)) * (d.Ho * d.rh) + (h_ * d.rh + qh)) * (d.Wo * d.rw) + (w_ * d.rw + qw);
+            dst = orow * cq + c;
+        } else {
+            dst = m * d.out_c + n;
+        }
+        *(i32x4*)((char*)p.out + dst * E::kBytes) = val;
+    }
+}
+
 // ------------------------------------------------------------------------------- MFMA step
 template <typename E> struct Mma;
 template <> struct Mma<BF16> {

@@ -224,6 +224,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             }
         return;
     }
+    if (stage_ok(p)) {   // LDS-staged, fully coalesced stores (the tap loop ended on a barrier: LDS is free)
+        const int64_t frame_row0 = ((int64_t)b * T + t) * H;
+        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) {
+            const int ph = lp / TW, pw = lp - ph * TW;
+            const bool ok = (h0 + ph) < H && (w0 + pw) < W;
+            return ok ? (frame_row0 + (h0 + ph)) * W + (w0 + pw) : p.M;
+        });
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < WCO; ++a)
 #pragma unroll
@@ -241,7 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 template <typename E, int BCO, int TH, int TW>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
-    constexpr size_t lds = (size_t)((HR * 128 + 255) / 256) * 256 + 2 * (size_t)BCO * 128;
+    constexpr size_t lds_main = (size_t)((HR * 128 + 255) / 256) * 256 + 2 * (size_t)BCO * 128;
+    constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, TH * TW>::kBytes;
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW>,

@@ -252,16 +252,17 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
         const int per = (C + KS - 1) / KS;
         if (cs < KS) {
             const int c0 = cs * per, c1 = min(C, c0 + per);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float a0 = 0.f, a1 = 0.f;
             int c = c0;
-            for (; c + 4 <= c1; c += 4) {
-                a0 += w1t[(int64_t)(c + 0) * hidden + k] * pooled[c + 0];
-                a1 += w1t[(int64_t)(c + 1) * hidden + k] * pooled[c + 1];
-                a2 += w1t[(int64_t)(c + 2) * hidden + k] * pooled[c + 2];
-                a3 += w1t[(int64_t)(c + 3) * hidden + k] * pooled[c + 3];
+            for (; c + 16 <= c1; c += 16) {          // 16 independent loads in flight per thread
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = w1t[(int64_t)(c + u) * hidden + k];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { a0 += w[u] * pooled[c + u]; a1 += w[u + 1] * pooled[c + u + 1]; }
             }
             for (; c < c1; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
-            slab[cs * hidden + k] = (a0 + a1) + (a2 + a3);
+            slab[cs * hidden + k] = a0 + a1;
         }
         __syncthreads();
         if (tid < hidden) {
@@ -277,16 +278,17 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
         const int per = (hidden + GS - 1) / GS;
         if (ks < GS) {
             const int k0 = ks * per, k1 = min(hidden, k0 + per);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float a0 = 0.f, a1 = 0.f;
             int k = k0;
-            for (; k + 4 <= k1; k += 4) {
-                a0 += w2t[(int64_t)(k + 0) * C + c] * hid[k + 0];
-                a1 += w2t[(int64_t)(k + 1) * C + c] * hid[k + 1];
-                a2 += w2t[(int64_t)(k + 2) * C + c] * hid[k + 2];
-                a3 += w2t[(int64_t)(k + 3) * C + c] * hid[k + 3];
+            for (; k + 16 <= k1; k += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = w2t[(int64_t)(k + u) * C + c];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { a0 += w[u] * hid[k + u]; a1 += w[u + 1] * hid[k + u + 1]; }
             }
             for (; k < k1; ++k) a0 += w2t[(int64_t)k * C + c] * hid[k];
-            slab[ks * C + c] = (a0 + a1) + (a2 + a3);
+            slab[ks * C + c] = a0 + a1;
         }
         __syncthreads();
         if (tid < C) {

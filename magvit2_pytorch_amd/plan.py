@@ -29,7 +29,8 @@ class PackedModel:
         self.cfg, self.dtype, self.ops = cfg, dtype, ops
         self.dt = P.dtype_code(dtype)
         self.stages: List[Stage] = parse_layers(cfg['layers'], cfg['init_dim'], cfg['max_dim'])
-        self.c_in_pad = int(os.environ.get('MV2_CONVIN_CPAD', '8' if dtype == torch.bfloat16 else '4'))
+        # 4-channel pixels: 8-byte (bf16) / 16-byte (fp32) rows; 16-byte gathers at 8-byte alignment verified on gfx950
+        self.c_in_pad = int(os.environ.get('MV2_CONVIN_CPAD', '4'))
         f = lambda k: sd[k].detach().float().cpu()
         dev = ops.to_device
         self.convs: Dict[str, P.PackedConv] = {}
