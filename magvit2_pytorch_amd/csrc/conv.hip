@@ -97,17 +97,21 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     // gather has two steps of flight time before it is waited for.
     i32x4 gw[2][RW], gp[2][RP];
 
-    auto load_seg = [&](int s) { return p.segs[s * segs_per_step + seg_sub]; };
+    // NB every load below is issued UNCONDITIONALLY (steps past the end read the out-of-range offset: zeros,
+    // no traffic).  A load inside a branch makes the wait-count pass fall back to vmcnt(0) at the next LDS
+    // write, which silently removes all flight time from the prefetch.
+    auto load_seg = [&](int s) { return p.segs[min(s, d.nsteps - 1) * segs_per_step + seg_sub]; };
     auto issue_loads = [&](int s, const mv2_seg sg, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
+        const bool live = s < s_end;
         const uint32_t so = (uint32_t)sg.elem_offset * (uint32_t)E::kBytes + seg_inner;
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
-            const bool ok = (rowmask[i] & sg.sel) == sg.sel;
+            const bool ok = live && (rowmask[i] & sg.sel) == sg.sel;
             const uint32_t vo = ok ? rowbase[i] + so : p.in_bytes;
             gp[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
-        const uint32_t wo_ = w_off0 + (uint32_t)s * w_step;
+        const uint32_t wo_ = live ? w_off0 + (uint32_t)s * w_step : p.w_bytes;
 #pragma unroll
         for (int i = 0; i < RW; ++i)
             gw[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 32u * 128u), 0, 0);
@@ -123,16 +127,20 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 
     if (s_begin < s_end) {
         // parity is relative to s_begin: step s_begin uses set / buffer 0
-        mv2_seg sg = load_seg(s_begin);
-        issue_loads(s_begin, sg, IC<0>{});
-        if (s_begin + 1 < s_end) { sg = load_seg(s_begin + 1); issue_loads(s_begin + 1, sg, IC<1>{}); }
-        if (s_begin + 2 < s_end) sg = load_seg(s_begin + 2);    // descriptors run ahead of their loads
+        // vmcnt retires IN ORDER: a descriptor fetched after a batch of gathers cannot be consumed before that
+        // batch has landed.  So every descriptor is fetched BEFORE the gathers issued in the same step.
+        const mv2_seg sg0 = load_seg(s_begin), sg1 = load_seg(s_begin + 1);
+        mv2_seg sg = load_seg(s_begin + 2);
+        issue_loads(s_begin, sg0, IC<0>{});
+        issue_loads(s_begin + 1, sg1, IC<1>{});
         write_lds(IC<0>{});
         __syncthreads();
         auto step = [&](int s, auto par_c) {
             constexpr int PAR = decltype(par_c)::value;
-            if (s + 2 < s_end) issue_loads(s + 2, sg, IC<PAR>{});
-            if (s + 3 < s_end) sg = load_seg(s + 3);
+            const mv2_seg nxt = load_seg(s + 3);
+            issue_loads(s + 2, sg, IC<PAR>{});
+            sg = nxt;
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the step (the scheduler would sink it)
             const char* base = smem + PAR * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[a], fp[b], acc[a][b]);
             }
-            if (s + 1 < s_end) write_lds(IC<PAR ^ 1>{});
+            write_lds(IC<PAR ^ 1>{});       // unconditional: after the last step it stores the zero dummy
             __syncthreads();
         };
         int s = s_begin;

@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     const int c_begin = z * p.chunks_per_split;
     const int c_end = min(p.nchunk, c_begin + p.chunks_per_split);
     const int kt = d.kt;
-    const int ab = p.ablate;
     const int G = (c_end - c_begin) * kt;           // halo groups: (chunk, it)
     const int S = G * 9;                            // taps
 
@@ -135,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < RW; ++i) wreg[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
         }
-        if (S > 1) {
-            const uint32_t wo_ = w_offset(1);
+        {
+            const uint32_t wo_ = (S > 1) ? w_offset(1) : p.w_bytes;
 #pragma unroll
             for (int i = 0; i < RW; ++i) wreg[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
         }
@@ -151,12 +150,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         auto tap = [&](int s, auto par_c) {
             constexpr int PAR = decltype(par_c)::value;
             const int g = s / 9, tp = s - g * 9;
-            if (s + 2 < S && !(ab & 2)) {
-                const uint32_t wo_ = w_offset(s + 2);
+            {   // UNCONDITIONAL issue (past-the-end taps read the out-of-range offset: zeros, no traffic): a load
+                // inside a branch makes the wait-count pass drain vmcnt(0) at the next LDS write, which
+                // silently removes all flight time from the prefetch.
+                const uint32_t wo_ = (s + 2 < S) ? w_offset(s + 2) : p.w_bytes;
 #pragma unroll
                 for (int i = 0; i < RW; ++i) wreg[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
             }
-            if (tp == 0 && g + 1 < G && !(ab & 1)) issue_halo(g + 1);
+            if (tp == 0 && g + 1 < G) issue_halo(g + 1);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap (the scheduler would sink them)
             const char* wb = wlds + PAR * WBUF;
             const int t3 = tp / 3;
             const int toff = t3 * HWD + (tp - 3 * t3);
@@ -178,13 +180,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < WPOS; ++bb) if (!(ab & 4)) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
+                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
             }
-            if (s + 1 < S) {
+            // (unconditional too: after the last tap it stores the zero-filled dummy into the idle buffer)
 #pragma unroll
-                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
-            }
-            if (tp == 8 && g + 1 < G && !(ab & 1)) {
+            for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
+            if (tp == 8 && g + 1 < G) {
                 __syncthreads();          // every wave is done with halo image g
                 write_halo();
             }
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     }
 
     // ---- epilogue (shared with conv.hip)
-    if (ab & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }
     const int nbase = n0 + wco * 32 * WCO;
     int64_t mrow[WPOS];
 #pragma unroll
