@@ -112,7 +112,29 @@ __device__ __forceinline__ float act_elu(float v) { return v > 0.f ? v : expm1f(
 __device__ __forceinline__ float act_silu(float v) { return v / (1.f + expf(-v)); }
 __device__ __forceinline__ float act_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
-#define MV2_LAUNCH_CHECK()                                   \
+// dtype-aware activations: the fp32 (id-parity) mode keeps libm accuracy; the bf16 mode (8 mantissa bits
+// on store) uses hardware exp / rcp forms that are ~10x cheaper in the conv epilogues.
+template <typename E> struct Act;
+template <> struct Act<F32> {
+    static __device__ __forceinline__ float elu(float v) { return act_elu(v); }
+    static __device__ __forceinline__ float silu(float v) { return act_silu(v); }
+    static __device__ __forceinline__ float gelu(float v) { return act_gelu(v); }
+};
+template <> struct Act<BF16> {
+    static __device__ __forceinline__ float elu(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
+    static __device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+    static __device__ __forceinline__ float gelu(float v) {
+        // erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), far below bf16 resolution
+        const float x = fabsf(v) * 0.70710678118654752440f;
+        const float t = __fdividef(1.f, 1.f + 0.3275911f * x);
+        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float erf_abs = 1.f - poly * __expf(-x * x);
+        const float erfv = v < 0.f ? -erf_abs : erf_abs;
+        return 0.5f * v * (1.f + erfv);
+    }
+};
+
+#define MV2_LAUNCH_CHECK()                                 \
     do {                                                     \
         hipError_t e_ = hipGetLastError();                   \
         if (e_ != hipSuccess) return (int)e_;                \

@@ -142,19 +142,34 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             sg = nxt;
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the step (the scheduler would sink it)
             const char* base = smem + PAR * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            // fragment reads software-pipelined over two register sets (see conv_halo.hip)
+            i32x4 fw[2][WCO], fp[2][WPOS];
+            auto read_frags = [&](int ks, auto set_c) {
+                constexpr int SET = decltype(set_c)::value;
                 const uint32_t ck = (uint32_t)(((ks * 2 + hi) ^ swz) << 4);
-                i32x4 fw[WCO], fp[WPOS];
 #pragma unroll
-                for (int a = 0; a < WCO; ++a) fw[a] = *(const i32x4*)(base + rd_w + a * 32 * 128 + ck);
+                for (int a = 0; a < WCO; ++a) fw[SET][a] = *(const i32x4*)(base + rd_w + a * 32 * 128 + ck);
 #pragma unroll
-                for (int b = 0; b < WPOS; ++b) fp[b] = *(const i32x4*)(base + rd_p + b * 32 * 128 + ck);
+                for (int b = 0; b < WPOS; ++b) fp[SET][b] = *(const i32x4*)(base + rd_p + b * 32 * 128 + ck);
+            };
+            auto mma_frags = [&](auto set_c) {
+                constexpr int SET = decltype(set_c)::value;
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                    for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[a], fp[b], acc[a][b]);
-            }
+                    for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[SET][a], fp[SET][b], acc[a][b]);
+            };
+            read_frags(0, IC<0>{});
+            read_frags(1, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<0>{});
+            read_frags(2, IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<1>{});
+            read_frags(3, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<0>{});
+            mma_frags(IC<1>{});
             write_lds(IC<PAR ^ 1>{});       // unconditional: after the last step it stores the zero dummy
             __syncthreads();
         };

@@ -54,10 +54,10 @@ __device__ __forceinline__ void epi_store4(const ConvParams& p, int64_t m, int n
         for (int j = 0; j < 4; ++j) if (n + j < d.co) v[j] += p.bias[n + j]; }
     if (d.act == MV2_ACT_ELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_elu(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = Act<E>::elu(v[j]);
     } else if (d.act == MV2_ACT_SILU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_silu(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = Act<E>::silu(v[j]);
     }
     if (d.store == MV2_STORE_ROWS) {
         int64_t o = m * d.out_c + n;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int n
     for (int j = 0; j < 4; ++j) {
         float xv = x[j], gv = g[j];
         if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
-        o[j] = act_gelu(gv) * xv;
+        o[j] = Act<E>::gelu(gv) * xv;
     }
     st4<E>(p.out, m * d.out_c + j0, o);
 }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
                     for (int j = 0; j < 4; ++j) {
                         float xv = acc[0][b][4 * g + j] * rs, gv = acc[1][b][4 * g + j] * rs;
                         if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
-                        o[j] = act_gelu(gv) * xv;
+                        o[j] = Act<E>::gelu(gv) * xv;
                     }
                     lds_put4<E>(rowp + (wco * 32 + off) * E::kBytes, o);
                 }
@@ -175,8 +175,8 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
                     for (int j = 0; j < 4; ++j) {
                         float x = acc[a][b][4 * g + j] * rs;
                         if (p.bias) x += p.bias[n + j];
-                        if (d.act == MV2_ACT_ELU) x = act_elu(x);
-                        else if (d.act == MV2_ACT_SILU) x = act_silu(x);
+                        if (d.act == MV2_ACT_ELU) x = Act<E>::elu(x);
+                        else if (d.act == MV2_ACT_SILU) x = Act<E>::silu(x);
                         v[j] = x;
                     }
                     if (p.residual && valid && n < d.co) {

@@ -169,19 +169,36 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
                 pbase[bb] = (uint32_t)pr * 128u;
                 psw[bb] = (uint32_t)((pr >> 1) & 7);
             }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            // fragment reads are software-pipelined over two register sets: the ds_reads of k-slice ks+1 are
+            // issued before the MFMAs of ks, so LDS latency hides behind four MFMAs instead of being paid
+            // four times per tap (PMC: waves sat 51 % in s_waitcnt with a single fragment set)
+            i32x4 fw[2][WCO], fp[2][WPOS];
+            auto read_frags = [&](int ks, auto set_c) {
+                constexpr int SET = decltype(set_c)::value;
                 const uint32_t ck = (uint32_t)(ks * 2 + hi);
-                i32x4 fw[WCO], fp[WPOS];
 #pragma unroll
-                for (int a = 0; a < WCO; ++a) fw[a] = *(const i32x4*)(wb + rd_w + a * 32 * 128 + ((ck ^ swz) << 4));
+                for (int a = 0; a < WCO; ++a) fw[SET][a] = *(const i32x4*)(wb + rd_w + a * 32 * 128 + ((ck ^ swz) << 4));
 #pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) fp[bb] = *(const i32x4*)(halo + pbase[bb] + ((ck ^ psw[bb]) << 4));
+                for (int bb = 0; bb < WPOS; ++bb) fp[SET][bb] = *(const i32x4*)(halo + pbase[bb] + ((ck ^ psw[bb]) << 4));
+            };
+            auto mma_frags = [&](auto set_c) {
+                constexpr int SET = decltype(set_c)::value;
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[a], fp[bb], acc[a][bb]);
-            }
+                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[SET][a], fp[SET][bb], acc[a][bb]);
+            };
+            read_frags(0, IC<0>{});
+            read_frags(1, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<0>{});
+            read_frags(2, IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<1>{});
+            read_frags(3, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frags(IC<0>{});
+            mma_frags(IC<1>{});
             // (unconditional too: after the last tap it stores the zero-filled dummy into the idle buffer)
 #pragma unroll
             for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
