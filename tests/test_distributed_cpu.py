@@ -1,0 +1,84 @@
+"""N > 1 path on CPU: two gloo processes shard a batch of clips (no data-path collective), tokenize
+their shards and all_gather the ids / all_reduce the metric sums — must equal the single-process
+result.  (On the GPU box the same code runs over RCCL: backend 'nccl'.)  The per-rank tokenizer here
+executes through the CPU emulation of the kernel semantics, so this exercises sharding + gathering,
+not the kernels."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from magvit2_pytorch_amd import README_LAYERS, VideoTokenizer
+from magvit2_pytorch_amd import distributed as D
+from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
+from oracle.ndhwc_ops import CpuOps
+
+KW = dict(image_size=32, init_dim=8, max_dim=32, codebook_size=256, layers=README_LAYERS)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_tok():
+    cfg = make_cfg(**KW)
+    tok = VideoTokenizer(**KW, seed=0)
+    tok.load_state_dict(init_state_dict(cfg, seed=0, randomize_se=True))
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    return tok
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    D.init_from_env('gloo')
+    tok = _make_tok()
+    video = torch.randn(total, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3))     # same global batch on every rank
+    codes = D.tokenize_sharded(tok, video, gather=True)
+    metrics = D.reconstruction_metrics_sharded(tok, video)
+    lo, hi = D.shard_bounds(total, rank, world)
+    q.put((rank, codes, metrics, (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [4, 3])      # 3: ragged split (2 + 1)
+def test_two_rank_sharding_matches_single_process(total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tok = _make_tok()
+    video = torch.randn(total, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3))
+    ref_codes = tok.tokenize(video)
+    recon = tok(video, return_recon=True)
+    ref_mse = (recon - video).pow(2).mean().item()
+    bounds = sorted(r[3] for r in res)
+    assert bounds[0][0] == 0 and bounds[-1][1] == total and bounds[0][1] == bounds[1][0]
+    for rank, codes, metrics, _ in res:
+        assert codes.shape == ref_codes.shape and torch.equal(codes, ref_codes)
+        assert abs(metrics['mse'] - ref_mse) < 1e-6 * max(1.0, ref_mse)
+
+
+def test_shard_bounds_partition():
+    for n in range(0, 20):
+        for w in (1, 2, 3, 8):
+            cuts = [D.shard_bounds(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
