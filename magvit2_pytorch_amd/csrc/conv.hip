@@ -332,7 +332,11 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     if (halo_eligible(d)) {
         L.halo = true;
         const int es = d.dtype == MV2_BF16 ? 2 : 4;
+        // tile menu of conv_halo.hip.  MV2_HALO_TILE=1 forces 64co x 128pos tiles above 64 channels (twice the
+        // blocks: less tail on the 512 block slots at batch 1, at 1.5 LDS fragment reads per MFMA instead of 1)
+        static const int tile_policy = getenv("MV2_HALO_TILE") ? atoi(getenv("MV2_HALO_TILE")) : 0;
         if (d.co <= 64) { L.t = {64, 256}; L.th = 16; L.tw = 16; }
+        else if (tile_policy == 1) { L.t = {64, 128}; L.th = 8; L.tw = 16; }
         else { L.t = {128, 128}; L.th = 8; L.tw = 16; }
         L.tiles_h = (d.Ho + L.th - 1) / L.th;
         L.tiles_w = (d.Wo + L.tw - 1) / L.tw;

@@ -2,36 +2,43 @@
 // conv: ~81 % of the path's FLOPs, reference magvit2_pytorch.py:937 / CausalConv3d :892-928).
 //
 // The generic kernel (conv.hip) gathers the activation tile once per tap: every input row is pulled
-// through the vector-memory path 27 times, and with a one-step prefetch the K loop runs at the
-// ~11 B/clk/CU latency-bound gather rate instead of the MFMA rate.  Here a block owns a TH x TW
-// rectangle of one output frame and stages the (TH+2) x (TW+2) input halo of one 128-byte channel
-// chunk of one input frame into LDS ONCE; the nine spatial taps of that frame are then just nine
-// row offsets into the same LDS image.  Global -> LDS activation traffic drops from 27x to
-// kt * (TH+2)(TW+2)/(TH*TW) ~ 4x; only the per-tap weight tile (BCO x 128 B, L2-resident) streams.
+// through the vector-memory path 27 times.  Here a block owns a TH x TW rectangle of one output frame and
+// stages the (TH+2) x (TW+2) input halo of one 128-byte channel chunk of one input frame into LDS ONCE;
+// the nine spatial taps of that frame are then nine row offsets into the same LDS image.  Global -> LDS
+// activation traffic drops from 27x to kt * (TH+2)(TW+2)/(TH*TW) ~ 4x; only the per-tap weight tile
+// (BCO x 128 B, L2-resident) streams.
 //
-// Pipeline: weights are register-prefetched two taps ahead (two register sets, selected statically by
-// tap parity) into a double-buffered LDS tile; the next group's halo is fetched into registers at the
-// first tap of the current group (two taps of flight before any younger load is waited for) and
-// written over the single halo image at the group boundary.  Zero padding (causal time front, "same"
-// space) comes for free from out-of-range buffer offsets returning 0.  Epilogue / split-K are shared
-// with conv.hip.
+// Schedule (all compile-time: a group = the 9 taps of one (chunk, frame); tap parity selects the weight
+// register set / LDS buffer):
+//   * weights: W(s+2) is issued into registers at the top of tap s, W(s+1) is written to the other LDS
+//     buffer after tap s's MFMAs -> two taps of flight;
+//   * halo: the next group's halo is issued at tap 0 of the current group and written at tap HWT into the
+//     OTHER halo image (DBH = double-buffered halo) -> ~6 taps of flight, no extra barrier; with a single
+//     image (DBH = false, tiles too big for two) it is written behind an extra barrier after tap 8;
+//   * every load is unconditional (past-the-end -> out-of-range offset, zeros, no traffic) so the
+//     compiler's wait counts stay exact (see conv.hip);
+//   * MFMA fragments are software-pipelined over two register sets.
+// Zero padding (causal time front, "same" space) comes from out-of-range buffer offsets returning 0.
+// Epilogue / split-K are shared with conv.hip.
 #include "conv_common.h"
 
-template <typename E, int BCO, int TH, int TW>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
-    constexpr int WCO = 2, WPOS = 2;
-    constexpr int NWPOS = BPOS / (32 * WPOS);
-    static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
+    constexpr int NWCO = BCO / (32 * WCO);
+    constexpr int NWPOS = 4 / NWCO;
+    constexpr int WPOS = BPOS / (32 * NWPOS);
+    static_assert(NWCO * NWPOS == 4 && WPOS >= 1 && NWPOS * WPOS * 32 == BPOS, "4 waves per block");
     constexpr int HWD = TW + 2;                    // halo row pitch (positions)
     constexpr int HR = (TH + 2) * HWD;             // halo rows
     constexpr int NH = (HR + 31) / 32;             // halo rows staged per thread
     constexpr int RW = BCO / 32;
     constexpr int HALO_BYTES = ((HR * 128 + 255) / 256) * 256;
     constexpr int WBUF = BCO * 128;
+    constexpr int HWT = 6;                         // tap at which the prefetched halo is written (DBH)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
-    char* const wlds = smem + HALO_BYTES;
+    char* const halo0 = smem;
+    char* const wlds = smem + (DBH ? 2 : 1) * HALO_BYTES;
 
     const mv2_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     const int wco = wave / NWPOS, wpos = wave % NWPOS;
     const uint32_t swz = (uint32_t)((l31 >> 1) & 7);
     const uint32_t rd_w = (uint32_t)(wco * 32 * WCO + l31) * 128u;
-    // this lane's two positions inside the tile -> halo row of their (dh = -1, dw = -1) tap
+    // this lane's positions inside the tile -> halo row of their (dh = -1, dw = -1) tap
     int prow0[WPOS];
 #pragma unroll
     for (int bb = 0; bb < WPOS; ++bb) {
@@ -101,10 +108,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     i32x4 hreg[NH];
     i32x4 wreg[2][RW];
 
+    // unconditional in instruction count: a group past the end (or a frame before t = 0) reads out of range
     auto issue_halo = [&](int g) {
         const int chunk = c_begin + g / kt, it = g % kt;
         const int t_in = t + it - d.pt;
-        const bool tok = t_in >= 0 && t_in < T;
+        const bool tok = g < G && t_in >= 0 && t_in < T;
         const uint32_t base = (uint32_t)(((int64_t)b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + hw_base;
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
@@ -115,63 +123,53 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
     };
-    auto write_halo = [&]() {
+    auto write_halo = [&](char* img) {
 #pragma unroll
         for (int i = 0; i < NH; ++i)
-            if (r0 + 32 * i < HR) *(i32x4*)(halo + lds_wr + i * 32 * 128) = hreg[i];
+            if (r0 + 32 * i < HR) *(i32x4*)(img + lds_wr + i * 32 * 128) = hreg[i];
     };
-    auto w_offset = [&](int s) {            // byte offset of this thread's first weight chunk of tap s
+    auto issue_w = [&](int s, auto set_c) {     // weights of tap s into register set SET
+        constexpr int SET = decltype(set_c)::value;
         const int g = s / 9, tp = s - g * 9;
         const int chunk = c_begin + g / kt, it = g % kt;
-        return w_off0 + (uint32_t)((it * 9 + tp) * p.nchunk + chunk) * w_step;
+        const uint32_t wo_ = (s < S) ? w_off0 + (uint32_t)((it * 9 + tp) * p.nchunk + chunk) * w_step : p.w_bytes;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) wreg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
     };
 
     if (S > 0) {
         // prologue: halo of group 0, weights of taps 0 and 1
         issue_halo(0);
-        {
-            const uint32_t wo_ = w_offset(0);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) wreg[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
-        }
-        {
-            const uint32_t wo_ = (S > 1) ? w_offset(1) : p.w_bytes;
-#pragma unroll
-            for (int i = 0; i < RW; ++i) wreg[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
-        }
-        write_halo();
+        issue_w(0, IC<0>{});
+        issue_w(1, IC<1>{});
+        write_halo(halo0);
 #pragma unroll
         for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * 32 * 128) = wreg[0][i];
         __syncthreads();
 
-        // one tap.  PAR = s & 1 is compile-time (register set / LDS weight buffer).  W(s+2) is issued into
-        // wreg[PAR] (free: W(s) went to LDS during tap s-1); W(s+1), issued one tap ago into wreg[PAR^1], is
-        // written to LDS buffer PAR^1 after this tap's MFMAs.
-        auto tap = [&](int s, auto par_c) {
+        // one tap of group g: TP = tap inside the group, PAR = (g*9 + TP) & 1, GP = g & 1 — all compile-time
+        auto tap = [&](int g, auto tp_c, auto par_c, auto gp_c) {
+            constexpr int TP = decltype(tp_c)::value;
             constexpr int PAR = decltype(par_c)::value;
-            const int g = s / 9, tp = s - g * 9;
-            {   // UNCONDITIONAL issue (past-the-end taps read the out-of-range offset: zeros, no traffic): a load
-                // inside a branch makes the wait-count pass drain vmcnt(0) at the next LDS write, which
-                // silently removes all flight time from the prefetch.
-                const uint32_t wo_ = (s + 2 < S) ? w_offset(s + 2) : p.w_bytes;
-#pragma unroll
-                for (int i = 0; i < RW; ++i) wreg[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
-            }
-            if (tp == 0 && g + 1 < G) issue_halo(g + 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap (the scheduler would sink them)
+            constexpr int GP = decltype(gp_c)::value;
+            const int s = g * 9 + TP;
+            issue_w(s + 2, IC<PAR>{});              // wreg[PAR] is free: W(s) went to LDS during tap s-1
+            if (TP == 0) issue_halo(g + 1);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap
             const char* wb = wlds + PAR * WBUF;
-            const int t3 = tp / 3;
-            const int toff = t3 * HWD + (tp - 3 * t3);
+            const char* himg = halo0 + (DBH ? GP * HALO_BYTES : 0);
+            constexpr int toff = (TP / 3) * HWD + (TP % 3);
             uint32_t pbase[WPOS], psw[WPOS];
 #pragma unroll
             for (int bb = 0; bb < WPOS; ++bb) {
-                const int pr = prow0[bb] + toff;
+                // opaque copy: without it loop-invariant code motion hoists the LDS addresses of all 18 unrolled
+                // taps out of the group loop and the kernel spills at 256 VGPRs
+                int pr_ = prow0[bb];
+                asm volatile("" : "+v"(pr_));
+                const int pr = pr_ + toff;
                 pbase[bb] = (uint32_t)pr * 128u;
                 psw[bb] = (uint32_t)((pr >> 1) & 7);
             }
-            // fragment reads are software-pipelined over two register sets: the ds_reads of k-slice ks+1 are
-            // issued before the MFMAs of ks, so LDS latency hides behind four MFMAs instead of being paid
-            // four times per tap (PMC: waves sat 51 % in s_waitcnt with a single fragment set)
             i32x4 fw[2][WCO], fp[2][WPOS];
             auto read_frags = [&](int ks, auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
                 for (int a = 0; a < WCO; ++a) fw[SET][a] = *(const i32x4*)(wb + rd_w + a * 32 * 128 + ((ck ^ swz) << 4));
 #pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) fp[SET][bb] = *(const i32x4*)(halo + pbase[bb] + ((ck ^ psw[bb]) << 4));
+                for (int bb = 0; bb < WPOS; ++bb) fp[SET][bb] = *(const i32x4*)(himg + pbase[bb] + ((ck ^ psw[bb]) << 4));
             };
             auto mma_frags = [&](auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
@@ -199,21 +197,28 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             mma_frags(IC<0>{});
             mma_frags(IC<1>{});
-            // (unconditional too: after the last tap it stores the zero-filled dummy into the idle buffer)
+            // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
 #pragma unroll
             for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
-            if (tp == 8 && g + 1 < G) {
-                __syncthreads();          // every wave is done with halo image g
-                write_halo();
+            if (DBH) {
+                if (TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
+            } else if (TP == 8) {
+                __syncthreads();                  // every wave is done with the single halo image
+                write_halo(halo0);
             }
             __syncthreads();
         };
-        int s = 0;
-        for (; s + 1 < S; s += 2) {
-            tap(s, IC<0>{});
-            tap(s + 1, IC<1>{});
-        }
-        if (s < S) tap(s, IC<0>{});
+        auto group = [&](int g, auto gp_c) {
+            constexpr int GP = decltype(gp_c)::value;
+            tap(g, IC<0>{}, IC<(GP + 0) & 1>{}, gp_c); tap(g, IC<1>{}, IC<(GP + 1) & 1>{}, gp_c);
+            tap(g, IC<2>{}, IC<(GP + 2) & 1>{}, gp_c); tap(g, IC<3>{}, IC<(GP + 3) & 1>{}, gp_c);
+            tap(g, IC<4>{}, IC<(GP + 4) & 1>{}, gp_c); tap(g, IC<5>{}, IC<(GP + 5) & 1>{}, gp_c);
+            tap(g, IC<6>{}, IC<(GP + 6) & 1>{}, gp_c); tap(g, IC<7>{}, IC<(GP + 7) & 1>{}, gp_c);
+            tap(g, IC<8>{}, IC<(GP + 8) & 1>{}, gp_c);
+        };
+        int g = 0;
+        for (; g + 1 < G; g += 2) { group(g, IC<0>{}); group(g + 1, IC<1>{}); }
+        if (g < G) group(g, IC<0>{});
     }
 
     // ---- epilogue (shared with conv.hip)
@@ -234,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
                 if (mrow[bb] >= p.M) continue;
                 float* row = p.ws + ((int64_t)z * p.ws_rows + mrow[bb]) * p.ws_cols + nbase + a * 32 + 4 * hi;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[a][bb][4 * g], acc[a][bb][4 * g + 1], acc[a][bb][4 * g + 2], acc[a][bb][4 * g + 3]};
-                    *(f32x4*)(row + 8 * g) = v;
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 v = {acc[a][bb][4 * gq], acc[a][bb][4 * gq + 1], acc[a][bb][4 * gq + 2], acc[a][bb][4 * gq + 3]};
+                    *(f32x4*)(row + 8 * gq) = v;
                 }
             }
         return;
@@ -255,37 +260,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
 #pragma unroll
         for (int bb = 0; bb < WPOS; ++bb) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int gq = 0; gq < 4; ++gq) {
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[a][bb][4 * g + j];
-                epi_store4<E>(p, mrow[bb], nbase + a * 32 + 8 * g + 4 * hi, v);
+                for (int j = 0; j < 4; ++j) v[j] = acc[a][bb][4 * gq + j];
+                epi_store4<E>(p, mrow[bb], nbase + a * 32 + 8 * gq + 4 * hi, v);
             }
         }
 }
 
-template <typename E, int BCO, int TH, int TW>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
-    constexpr size_t lds_main = (size_t)((HR * 128 + 255) / 256) * 256 + 2 * (size_t)BCO * 128;
+    constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
+    constexpr size_t lds_main = (DBH ? 2 : 1) * halo_bytes + 2 * (size_t)BCO * 128;
     constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, TH * TW>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH>), grid, dim3(256), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
 
+// tile menu: (BCO, TH x TW):  (64, 16x16) one image | (128, 8x16) two images | (64, 8x16) two images, 32co x 64pos waves
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st) {
     const bool bf = p.d.dtype == MV2_BF16;
-    if (bco == 64 && th == 16 && tw == 16) return bf ? launch_one<BF16, 64, 16, 16>(p, st) : launch_one<F32, 64, 16, 16>(p, st);
-    if (bco == 128 && th == 8 && tw == 16) return bf ? launch_one<BF16, 128, 8, 16>(p, st) : launch_one<F32, 128, 8, 16>(p, st);
+    if (bco == 64 && th == 16 && tw == 16)
+        return bf ? launch_one<BF16, 64, 16, 16, 2, false>(p, st) : launch_one<F32, 64, 16, 16, 2, false>(p, st);
+    if (bco == 128 && th == 8 && tw == 16)
+        return bf ? launch_one<BF16, 128, 8, 16, 2, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true>(p, st);
+    if (bco == 64 && th == 8 && tw == 16)
+        return bf ? launch_one<BF16, 64, 8, 16, 1, true>(p, st) : launch_one<F32, 64, 8, 16, 1, true>(p, st);
     return MV2_EINVAL;
 }
