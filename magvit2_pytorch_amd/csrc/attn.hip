@@ -1,6 +1,7 @@
 // Axial softmax attention with memory key/values, and Taylor-series linear attention.
-// Round-1 form: fp32 VALU arithmetic with LDS-staged K/V tiles (the contractions are <1% of the
-// path's FLOPs at the benchmark shapes); the MFMA QK^T / PV form is the next step.
+// bf16 space attention runs on MFMA (attn_mfma_kernel: QK^T and PV as v_mfma_f32_32x32x16_bf16); the fp32
+// (id-parity) mode and the tiny causal time attention use fp32 VALU kernels.
+#include <cstdlib>
 #include "common.h"
 
 struct AttnParams {
@@ -147,6 +148,142 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
     }
 }
 
+// ---- MFMA flash-style attention (bf16, non-causal, n >= 64: the space-attention case).
+// Block = 4 waves x 32 queries of one (sequence, head); keys (memory kv first, then tokens) are staged in
+// LDS chunks of up to AT_KC keys: K row-major [key][32 d] (64-byte rows, chunk ^ ((key>>2)&3) swizzle) and
+// V TRANSPOSED [32 dv][key] (pitch chosen bank-conflict free).  Per 32-key tile a wave computes
+//     S^T[key][query] = K . Q^T        (2 x v_mfma_f32_32x32x16_bf16; "swapped QK^T": lane = query)
+// so the online-softmax statistics of a query live in one lane pair, and
+//     O^T[dv][query] += V^T . P^T      (2 MFMAs)
+// where the P^T operand is exactly the lane's own 8 exponentiated scores per k-step (the k order of the
+// contraction is permuted identically on the V^T side), so no cross-lane movement or LDS round trip of P.
+#define AT_KC 320
+#define AT_VPITCH (AT_KC * 2 + 8)      // bytes per V^T row: 162 dwords -> 32 lanes x 2 dwords hit 64 distinct banks
+
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char Ks[AT_KC * 64];
+    __shared__ __attribute__((aligned(16))) char Vt[32 * AT_VPITCH];
+    const int seq = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int q_idx = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_ok = q_idx < p.n;
+    const int ld = 3 * p.heads * 32;
+    const int KL = p.n_mem + p.n;
+    // Q fragments (B operand of S^T): this lane's query row, d slots [step*16 + hi*8, +8)
+    i32x4 qf[2];
+    {
+        const char* qp = (const char*)p.qkv + (attn_row(p, seq, q_ok ? q_idx : 0) * ld + h * 32) * 2;
+        qf[0] = *(const i32x4*)(qp + hi * 16);
+        qf[1] = *(const i32x4*)(qp + 32 + hi * 16);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float scale = 0.17677669529663687f;
+
+    for (int k0 = 0; k0 < KL; k0 += AT_KC) {
+        const int nk = min(AT_KC, KL - k0);
+        __syncthreads();
+        // ---- stage: item = (key, which); K rows swizzled, V transposed
+        // (keys of the last partial 32-tile are zero-filled: their scores are masked to -inf, but a stale
+        //  NaN bit pattern in V^T would still poison the PV MFMA through 0 * NaN)
+        const int nk32 = ((nk + 31) / 32) * 32;
+        for (int it = tid; it < nk32 * 2; it += 256) {
+            const int key = it >> 1, which = it & 1;
+            const int gk = k0 + key;
+            i32x4 v[4];
+            if (key >= nk) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) { v[c4][0] = 0; v[c4][1] = 0; v[c4][2] = 0; v[c4][3] = 0; }
+            } else if (gk < p.n_mem) {
+                const float* src = p.mem_kv + (((int64_t)which * p.heads + h) * p.n_mem + gk) * 32;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    v[c4][0] = (int)pack_bf2(src[c4 * 8 + 0], src[c4 * 8 + 1]); v[c4][1] = (int)pack_bf2(src[c4 * 8 + 2], src[c4 * 8 + 3]);
+                    v[c4][2] = (int)pack_bf2(src[c4 * 8 + 4], src[c4 * 8 + 5]); v[c4][3] = (int)pack_bf2(src[c4 * 8 + 6], src[c4 * 8 + 7]);
+                }
+            } else {
+                const char* src = (const char*)p.qkv + (attn_row(p, seq, gk - p.n_mem) * ld + ((1 + which) * p.heads + h) * 32) * 2;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) v[c4] = *(const i32x4*)(src + c4 * 16);
+            }
+            if (which == 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) *(i32x4*)(Ks + key * 64 + ((c4 ^ ((key >> 2) & 3)) << 4)) = v[c4];
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned u = (unsigned)v[c4][w];
+                        const int dv = c4 * 8 + w * 2;
+                        *(unsigned short*)(Vt + dv * AT_VPITCH + key * 2) = (unsigned short)(u & 0xffffu);
+                        *(unsigned short*)(Vt + (dv + 1) * AT_VPITCH + key * 2) = (unsigned short)(u >> 16);
+                    }
+            }
+        }
+        __syncthreads();
+        const int ntile = (nk + 31) / 32;
+        for (int kb = 0; kb < ntile; ++kb) {
+            // S^T tile: rows = keys kb*32 + l31 (A operand from LDS), cols = this wave's 32 queries
+            const int krow = kb * 32 + l31;
+            const int ksw = (krow >> 2) & 3;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const i32x4 kf = *(const i32x4*)(Ks + krow * 64 + (((st * 2 + hi) ^ ksw) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s, 0, 0, 0);
+            }
+            // reg r <-> key_local = 8*(r>>2) + 4*hi + (r&3); lane <-> query
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                s[r] = kl < nk ? s[r] * scale : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = __expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            // O^T += V^T . P^T : k-step j uses this lane's scores r = 8j..8j+7, i.e. keys 16j + {0..3, 8..11} + 4*hi
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                i32x4 pf;
+                pf[0] = (int)pack_bf2(s[8 * j + 0], s[8 * j + 1]); pf[1] = (int)pack_bf2(s[8 * j + 2], s[8 * j + 3]);
+                pf[2] = (int)pack_bf2(s[8 * j + 4], s[8 * j + 5]); pf[3] = (int)pack_bf2(s[8 * j + 6], s[8 * j + 7]);
+                const char* vrow = Vt + l31 * AT_VPITCH + (kb * 32 + 16 * j + 4 * hi) * 2;
+                const i32x2 va = *(const i32x2*)(vrow), vb = *(const i32x2*)(vrow + 16);
+                i32x4 vf; vf[0] = va[0]; vf[1] = va[1]; vf[2] = vb[0]; vf[3] = vb[1];
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o, 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q_ok) {
+        const float inv = 1.f / l;
+        char* op = (char*)p.out + (attn_row(p, seq, q_idx) * (p.heads * 32) + h * 32) * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {      // reg r <-> dv = 8*(r>>2) + 4*hi + (r&3)
+            i32x2 w;
+            w[0] = (int)pack_bf2(o[4 * g + 0] * inv, o[4 * g + 1] * inv);
+            w[1] = (int)pack_bf2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *(i32x2*)(op + (8 * g + 4 * hi) * 2) = w;
+        }
+    }
+}
+
 extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, void* out, int nseq, int n, int heads,
                              int dim_head, int n_mem, int causal, int seq_inner, int64_t seq_outer_stride,
                              int64_t tok_stride, void* stream) {
@@ -154,6 +291,14 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
     if (dim_head != 32 || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
     AttnParams p{qkv, mem_kv, out, nseq, n, heads, n_mem, causal, seq_inner, seq_outer_stride, tok_stride};
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_mfma = getenv("MV2_ATTN_VALU") != nullptr;
+    if (dtype == MV2_BF16 && !causal && n >= 64 && !no_mfma) {
+        if (nseq > 65535) return MV2_EINVAL;
+        dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)nseq);
+        hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), 0, st, p);
+        MV2_LAUNCH_CHECK();
+        return MV2_OK;
+    }
     if (n < 64) {
         const int64_t total = (int64_t)nseq * heads * n;
         const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -337,7 +337,9 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
         static const int tile_policy = getenv("MV2_HALO_TILE") ? atoi(getenv("MV2_HALO_TILE")) : 0;
         if (d.co <= 64) { L.t = {64, 256}; L.th = 16; L.tw = 16; }
         else if (tile_policy == 1) { L.t = {64, 128}; L.th = 8; L.tw = 16; }
+        else if (tile_policy == 2 && d.Ho >= 16 && d.Wo >= 16) { L.t = {128, 256}; L.th = 16; L.tw = 16; }   // 8 waves, 1 block / CU
         else { L.t = {128, 128}; L.th = 8; L.tw = 16; }
+        const int slots_per_cu = (L.t.bco == 128 && L.t.bpos == 256) ? 1 : 2;
         L.tiles_h = (d.Ho + L.th - 1) / L.th;
         L.tiles_w = (d.Wo + L.tw - 1) / L.tw;
         L.nchunk = (d.Ci * es) / 128;
@@ -348,7 +350,8 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
             sk = 1;
             const int64_t blocks = (int64_t)L.n_co_tiles * L.n_pos_tiles;
             const int cus = device_cus();
-            if (blocks < cus + cus / 2) sk = (int)((2 * cus + blocks - 1) / blocks);
+            const int64_t slots = (int64_t)cus * slots_per_cu;
+            if (blocks * 4 < slots * 3) sk = (int)((slots + blocks - 1) / blocks);
         }
         if (sk > L.nchunk) sk = L.nchunk;
         if (sk < 1) sk = 1;

@@ -132,7 +132,7 @@ __device__ __forceinline__ bool stage_ok(const ConvParams& p) {
     return p.d.store != MV2_STORE_NCTHW_F32 && ((p.d.out_c * es) % 16) == 0 && (p.d.co % (16 / es)) == 0;
 }
 
-template <typename E, int BCO, int BPOS, int WCO, int WPOS, typename RowFn>
+template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typename RowFn>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
                                                 int wpos, int tid, RowFn row_of) {
     const mv2_conv_desc& d = p.d;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
     const int nvalid = geglu ? d.out_c : d.co;                    // valid output columns
     const int cpr = width * E::kBytes / 16;
     const int total = BPOS * cpr;
-    for (int q = tid; q < total; q += 256) {
+    for (int q = tid; q < total; q += NT) {
         const int lp = q / cpr, ch = q - lp * cpr;
         const int n = nbase + ch * E::kVec;
         if (n >= nvalid) continue;

@@ -22,17 +22,20 @@
 // Epilogue / split-K are shared with conv.hip.
 #include "conv_common.h"
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
+    constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
+    constexpr int RPP = NT / 8;                    // rows staged per pass (8 lanes per 128-byte row)
     constexpr int NWCO = BCO / (32 * WCO);
-    constexpr int NWPOS = 4 / NWCO;
+    constexpr int NWPOS = NWV / NWCO;
     constexpr int WPOS = BPOS / (32 * NWPOS);
-    static_assert(NWCO * NWPOS == 4 && WPOS >= 1 && NWPOS * WPOS * 32 == BPOS, "4 waves per block");
+    static_assert(NWCO * NWPOS == NWV && WPOS >= 1 && NWPOS * WPOS * 32 == BPOS, "wave tiling");
     constexpr int HWD = TW + 2;                    // halo row pitch (positions)
     constexpr int HR = (TH + 2) * HWD;             // halo rows
-    constexpr int NH = (HR + 31) / 32;             // halo rows staged per thread
-    constexpr int RW = BCO / 32;
+    constexpr int NH = (HR + RPP - 1) / RPP;       // halo rows staged per thread
+    constexpr int RW = BCO / RPP;
+    static_assert(RW >= 1, "weight rows per thread");
     constexpr int HALO_BYTES = ((HR * 128 + 255) / 256) * 256;
     constexpr int WBUF = BCO * 128;
     constexpr int HWT = 6;                         // tap at which the prefetched halo is written (DBH)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     uint32_t hmask = 0;
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-        const int hr = r0 + 32 * i;
+        const int hr = r0 + RPP * i;
         if (hr < HR) {
             const int hy = hr / HWD, hx = hr - hy * HWD;
             const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         const uint32_t base = (uint32_t)(((int64_t)b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + hw_base;
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
-            const int hr = r0 + 32 * i;
+            const int hr = r0 + RPP * i;
             const int hy = hr / HWD, hx = hr - hy * HWD;
             const bool ok = tok && ((hmask >> i) & 1u);
             const uint32_t vo = ok ? base + (uint32_t)(hy * W + hx) * row_bytes : p.in_bytes;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     auto write_halo = [&](char* img) {
 #pragma unroll
         for (int i = 0; i < NH; ++i)
-            if (r0 + 32 * i < HR) *(i32x4*)(img + lds_wr + i * 32 * 128) = hreg[i];
+            if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * 128) = hreg[i];
     };
     auto issue_w = [&](int s, auto set_c) {     // weights of tap s into register set SET
         constexpr int SET = decltype(set_c)::value;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         const int chunk = c_begin + g / kt, it = g % kt;
         const uint32_t wo_ = (s < S) ? w_off0 + (uint32_t)((it * 9 + tp) * p.nchunk + chunk) * w_step : p.w_bytes;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) wreg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 4096u), 0, 0);
+        for (int i = 0; i < RW; ++i) wreg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)(i * RPP * 128)), 0, 0);
     };
 
     if (S > 0) {
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         issue_w(1, IC<1>{});
         write_halo(halo0);
 #pragma unroll
-        for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * 32 * 128) = wreg[0][i];
+        for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * RPP * 128) = wreg[0][i];
         __syncthreads();
 
         // one tap of group g: TP = tap inside the group, PAR = (g*9 + TP) & 1, GP = g & 1 — all compile-time
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
             mma_frags(IC<1>{});
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
 #pragma unroll
-            for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * 32 * 128) = wreg[PAR ^ 1][i];
+            for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[PAR ^ 1][i];
             if (DBH) {
                 if (TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
             } else if (TP == 8) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
     }
     if (stage_ok(p)) {   // LDS-staged, fully coalesced stores (the tap loop ended on a barrier: LDS is free)
         const int64_t frame_row0 = ((int64_t)b * T + t) * H;
-        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) {
+        staged_epilogue<E, BCO, BPOS, WCO, WPOS, NT>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) {
             const int ph = lp / TW, pw = lp - ph * TW;
             const bool ok = (h0 + ph) < H && (w0 + pw) < W;
             return ok ? (frame_row0 + (h0 + ph)) * W + (w0 + pw) : p.M;
@@ -269,23 +272,23 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvParams p) {
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
     constexpr size_t lds_main = (DBH ? 2 : 1) * halo_bytes + 2 * (size_t)BCO * 128;
     constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, TH * TW>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -294,10 +297,12 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st) {
     const bool bf = p.d.dtype == MV2_BF16;
     if (bco == 64 && th == 16 && tw == 16)
-        return bf ? launch_one<BF16, 64, 16, 16, 2, false>(p, st) : launch_one<F32, 64, 16, 16, 2, false>(p, st);
+        return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4>(p, st);
     if (bco == 128 && th == 8 && tw == 16)
-        return bf ? launch_one<BF16, 128, 8, 16, 2, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true>(p, st);
+        return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4>(p, st);
     if (bco == 64 && th == 8 && tw == 16)
-        return bf ? launch_one<BF16, 64, 8, 16, 1, true>(p, st) : launch_one<F32, 64, 8, 16, 1, true>(p, st);
+        return bf ? launch_one<BF16, 64, 8, 16, 1, true, 4>(p, st) : launch_one<F32, 64, 8, 16, 1, true, 4>(p, st);
+    if (bco == 128 && th == 16 && tw == 16)     // 8 waves, one block per CU: weight tile staged once per 256 positions
+        return bf ? launch_one<BF16, 128, 16, 16, 2, true, 8>(p, st) : launch_one<F32, 128, 16, 16, 2, true, 8>(p, st);
     return MV2_EINVAL;
 }
