@@ -20,9 +20,10 @@
 //   * MFMA fragments are software-pipelined over two register sets.
 // Zero padding (causal time front, "same" space) comes from out-of-range buffer offsets returning 0.
 // Epilogue / split-K are shared with conv.hip.
+#include <cstdlib>
 #include "conv_common.h"
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
     constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
@@ -109,7 +110,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
 
     i32x4 hreg[NH];
-    i32x4 wreg[2][RW];
+    i32x4 wreg[2][GLW ? 1 : RW];
+    // GLW: the weight tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+    // ds_write_b128 at ~79 B/clk).  The LDS image of a DMA is lane-linear (wave base + lane * 16), so the
+    // chunk swizzle is applied to the SOURCE address: lane (row = tid >> 3, physical chunk = tid & 7) fetches
+    // logical chunk (tid & 7) ^ ((row >> 1) & 7).  __syncthreads() drains the DMA (vmcnt(0)) every tap.
+    const int wv_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma_w = [&](int s, int buf) {
+        const int sc = s < S ? s : S - 1;              // past the end: re-fetch the last tile into the idle buffer
+        const int g = sc / 9, tp = sc - g * 9;
+        const int chunk = c_begin + g / kt, it = g % kt;
+        const char* src = (const char*)p.wp + (size_t)((it * 9 + tp) * p.nchunk + chunk) * w_step + (size_t)(n0 + r0) * 128u
+                          + (size_t)((c ^ ((r0 >> 1) & 7)) << 4);
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * RPP * 128),
+                                             (__attribute__((address_space(3))) void*)(wlds + buf * WBUF + (i * RPP + wv_u * 8) * 128), 16, 0, 0);
+    };
 
     // unconditional in instruction count: a group past the end (or a frame before t = 0) reads out of range
     auto issue_halo = [&](int g) {
@@ -143,11 +160,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
     if (S > 0) {
         // prologue: halo of group 0, weights of taps 0 and 1
         issue_halo(0);
-        issue_w(0, IC<0>{});
-        issue_w(1, IC<1>{});
+        if constexpr (GLW) {
+            dma_w(0, 0);
+        } else {
+            issue_w(0, IC<0>{});
+            issue_w(1, IC<1>{});
+        }
         write_halo(halo0);
+        if constexpr (!GLW) {
 #pragma unroll
-        for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * RPP * 128) = wreg[0][i];
+            for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + lds_wr + i * RPP * 128) = wreg[0][i];
+        }
         __syncthreads();
 
         // one tap of group g: TP = tap inside the group, PAR = (g*9 + TP) & 1, GP = g & 1 — all compile-time
@@ -156,7 +179,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             constexpr int PAR = decltype(par_c)::value;
             constexpr int GP = decltype(gp_c)::value;
             const int s = g * 9 + TP;
-            issue_w(s + 2, IC<PAR>{});              // wreg[PAR] is free: W(s) went to LDS during tap s-1
+            if constexpr (GLW) dma_w(s + 1, PAR ^ 1);   // buffer PAR^1 was last read in tap s-1 (barrier passed)
+            else issue_w(s + 2, IC<PAR>{});         // wreg[PAR] is free: W(s) went to LDS during tap s-1
             if (TP == 0) issue_halo(g + 1);
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap
             const char* wb = wlds + PAR * WBUF;
@@ -201,8 +225,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             mma_frags(IC<0>{});
             mma_frags(IC<1>{});
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
+            if constexpr (!GLW) {
 #pragma unroll
-            for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[PAR ^ 1][i];
+                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[PAR ^ 1][i];
+            }
             if (DBH) {
                 if (TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
             } else if (TP == 8) {
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
@@ -282,13 +308,13 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV>), grid, dim3(64 * NWV), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -298,6 +324,11 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
     const bool bf = p.d.dtype == MV2_BF16;
     if (bco == 64 && th == 16 && tw == 16)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4>(p, st);
+    static const bool glw = getenv("MV2_HALO_GLDS") != nullptr;   // weight tile by LDS-DMA (A/B switch)
+    if (bco == 128 && th == 8 && tw == 16 && glw)
+        return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
+    if (bco == 64 && th == 16 && tw == 16 && glw)
+        return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
     if (bco == 128 && th == 8 && tw == 16)
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4>(p, st);
     if (bco == 64 && th == 8 && tw == 16)
