@@ -114,6 +114,16 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
              const float* bias, const float* rowscale, const void* residual, void* out,
              void* workspace, size_t workspace_bytes, void* stream);
 
+/* mv2_conv_pw — fused front half of a ResidualUnit (M:937-940): the kt x 3 x 3 causal convolution described by
+ * `d` (+ bias, d->act), immediately followed by a 1x1x1 convolution over the same channels (+ bias2, act2),
+ * without writing the intermediate tensor: out = act2(W2 . act(conv(in) + bias) + bias2).
+ * Only for bf16, stride 1, "same"/causal padding, C_out in {64, 128} (a block then owns every channel of its
+ * positions); mv2_conv_pw_eligible() says whether a descriptor qualifies (else issue two mv2_conv calls).
+ * wp2: pointwise weights packed like any 1x1x1 conv: [C/64][128][128 B].  No workspace. */
+int mv2_conv_pw_eligible(const mv2_conv_desc* d);
+int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                const float* bias, const void* wp2, const float* bias2, int act2, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * mv2_video_to_ndhwc — API-edge layout change + zero padding.
  * Replaces: pad_at_dim M:1537 and conv_in's F.pad M:927 (the 7x7x7 halo is materialised once so

@@ -446,6 +446,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     ConvParams p;
     p.d = *d; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = rowscale; p.residual = residual;
     p.out = out; p.ws = (float*)workspace;
+    p.wp2 = nullptr; p.bias2 = nullptr; p.act2 = MV2_ACT_NONE;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = L.M; p.lg_seg_chunks = ilog2(d->seg_bytes / 16);
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
@@ -462,6 +463,40 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     }
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == MV2_BF16 ? launch_dtype<BF16>(p, L, st) : launch_dtype<F32>(p, L, st);
+}
+
+// fused 3x3 causal conv + activation + 1x1x1 conv + activation (ResidualUnit front half), bf16, C <= 128
+extern "C" int mv2_conv_pw_eligible(const mv2_conv_desc* d) {
+    if (!d || validate(*d) != MV2_OK) return 0;
+    if (d->dtype != MV2_BF16 || !halo_eligible(*d)) return 0;
+    if (d->co > 128 || (d->co != 64 && d->co != 128) || d->store != MV2_STORE_ROWS || d->out_c != d->co) return 0;
+    if (d->act == MV2_ACT_GEGLU) return 0;
+    static const bool off = getenv("MV2_NO_FUSE_PW") != nullptr;
+    return off ? 0 : 1;
+}
+
+extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                           const float* bias, const void* wp2, const float* bias2, int act2, void* out, void* stream) {
+    if (!d || !in || !wp || !segs || !wp2 || !out) return MV2_EINVAL;
+    if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
+    if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU && act2 != MV2_ACT_SILU) return MV2_EINVAL;
+    if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
+    mv2_conv_desc dd = *d;
+    dd.splitk = 1;                               // the fused stage needs the whole reduction in one block
+    const Launch L = plan_launch(dd);
+    if (!L.halo || L.n_co_tiles != 1 || L.splitk != 1) return MV2_EINVAL;
+    ConvParams p;
+    p.d = dd; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = nullptr; p.residual = nullptr;
+    p.out = out; p.ws = nullptr;
+    p.wp2 = wp2; p.bias2 = bias2; p.act2 = act2;
+    p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)((size_t)dd.nsteps * dd.co_pad * 128);
+    p.M = L.M; p.lg_seg_chunks = ilog2(dd.seg_bytes / 16);
+    p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
+    p.steps_per_split = L.steps_per_split; p.splitk = 1;
+    p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
+    p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
+    p.ablate = 0;
+    return mv2_launch_halo(p, L.t.bco, L.th, L.tw, (hipStream_t)stream);
 }
 
 extern "C" int mv2_abi_version(void) { return MV2_ABI_VERSION; }

@@ -27,7 +27,11 @@ struct ConvParams {
     int64_t ws_rows;
     // halo-tiled 3x3 variant (conv_halo.hip)
     int32_t tiles_h, tiles_w, nchunk, chunks_per_split;
-    int32_t ablate;   // profiling aid (env MV2_ABLATE): 1 no halo refetch, 2 no weight refetch, 4 no MFMA, 8 no epilogue
+    int32_t ablate;   // runtime A/B switches for experiments (env MV2_ABLATE), see conv_halo.hip
+    // fused second stage (mv2_conv_pw): 1x1x1 conv over the block's own output channels
+    const void* wp2;
+    const float* bias2;
+    int32_t act2;
 };
 
 // conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice

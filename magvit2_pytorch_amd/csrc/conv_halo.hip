@@ -23,6 +23,113 @@
 #include <cstdlib>
 #include "conv_common.h"
 
+
+// ---- fused epilogue of mv2_conv_pw (bf16): out = act2(W2 . act1(conv3x3 + b1) + b2) without leaving the CU.
+// Valid when the block owns every output channel of its positions (one co tile, no split-K).  The finished
+// first-stage tile is dropped into LDS as [position][channel] bf16 (pitch chosen so that the MFMA B-operand
+// reads of 32 consecutive rows are bank-conflict free), the C x C pointwise weights are staged next to it
+// in the usual swizzled [row][8 x 16 B] image, a second MFMA GEMM runs out of LDS, and the result replaces
+// the tile and is streamed out with whole-row 16-byte stores.  Replaces: nn.ELU + nn.Conv3d(dim, dim, 1) +
+// nn.ELU of ResidualUnit (reference magvit2_pytorch.py:938-940) and one full write + read of the tensor.
+template <int BCO, int BPOS, int WCO, int WPOS, int NT, typename RowFn>
+__device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int wco, int wpos,
+                                                         int tid, RowFn row_of) {
+    typedef BF16 E;
+    const mv2_conv_desc& d = p.d;
+    constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
+    constexpr int TILE = ((StageCfg<E, BCO, BPOS>::kBytes + 255) / 256) * 256;
+    constexpr int NS2 = BCO * 2 / 128;                 // K steps of the pointwise conv (64 bf16 each)
+    char* const t1 = lds;
+    char* const w2 = lds + TILE;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    // ---- stage 1 values -> tile
+#pragma unroll
+    for (int b = 0; b < WPOS; ++b) {
+        const int lp = wpos * 32 * WPOS + b * 32 + l31;
+        char* rowp = t1 + lp * PITCH;
+#pragma unroll
+        for (int a = 0; a < WCO; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wco * 32 * WCO + a * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[a][b][4 * g + j];
+                    if (p.bias) x += p.bias[col + j];
+                    if (d.act == MV2_ACT_ELU) x = Act<E>::elu(x);
+                    else if (d.act == MV2_ACT_SILU) x = Act<E>::silu(x);
+                    v[j] = x;
+                }
+                lds_put4<E>(rowp + col * 2, v);
+            }
+    }
+    // ---- pointwise weights -> LDS (swizzled rows)
+    for (int q = tid; q < NS2 * BCO * 8; q += NT) {
+        const int st = q / (BCO * 8), rem = q - st * BCO * 8;
+        const int row = rem >> 3, c = rem & 7;
+        const i32x4 v = *(const i32x4*)((const char*)p.wp2 + ((size_t)st * d.co_pad + row) * 128 + c * 16);
+        *(i32x4*)(w2 + (st * BCO + row) * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+    __syncthreads();
+    // ---- second GEMM out of LDS
+#pragma unroll
+    for (int a = 0; a < WCO; ++a)
+#pragma unroll
+        for (int b = 0; b < WPOS; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const uint32_t swz = (uint32_t)((l31 >> 1) & 7);
+#pragma unroll
+    for (int st = 0; st < NS2; ++st)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t ck = (uint32_t)(ks * 2 + hi);
+            i32x4 fw[WCO], fp[WPOS];
+#pragma unroll
+            for (int a = 0; a < WCO; ++a) fw[a] = *(const i32x4*)(w2 + (st * BCO + wco * 32 * WCO + a * 32 + l31) * 128 + ((ck ^ swz) << 4));
+#pragma unroll
+            for (int b = 0; b < WPOS; ++b) fp[b] = *(const i32x4*)(t1 + (wpos * 32 * WPOS + b * 32 + l31) * PITCH + st * 128 + ck * 16);
+#pragma unroll
+            for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[a], fp[b], acc[a][b]);
+        }
+    __syncthreads();      // every wave is done reading the stage-1 tile
+    // ---- stage 2 values -> tile, then coalesced rows
+#pragma unroll
+    for (int b = 0; b < WPOS; ++b) {
+        const int lp = wpos * 32 * WPOS + b * 32 + l31;
+        char* rowp = t1 + lp * PITCH;
+#pragma unroll
+        for (int a = 0; a < WCO; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wco * 32 * WCO + a * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[a][b][4 * g + j];
+                    if (p.bias2) x += p.bias2[col + j];
+                    if (p.act2 == MV2_ACT_ELU) x = Act<E>::elu(x);
+                    else if (p.act2 == MV2_ACT_SILU) x = Act<E>::silu(x);
+                    v[j] = x;
+                }
+                lds_put4<E>(rowp + col * 2, v);
+            }
+    }
+    __syncthreads();
+    constexpr int cpr = BCO * 2 / 16;
+    for (int q = tid; q < BPOS * cpr; q += NT) {
+        const int lp = q / cpr, ch = q - lp * cpr;
+        const int n = ch * 8;
+        if (n >= d.co) continue;
+        const int64_t m = row_of(lp);
+        if (m >= p.M) continue;
+        *(i32x4*)((char*)p.out + (m * d.out_c + n) * 2) = *(const i32x4*)(t1 + lp * PITCH + ch * 16);
+    }
+}
+
 template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
@@ -67,6 +174,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
     const int c_begin = z * p.chunks_per_split;
     const int c_end = min(p.nchunk, c_begin + p.chunks_per_split);
     const int kt = d.kt;
+    const bool prio = (p.ablate & 1) != 0;          // runtime A/B switches (env MV2_ABLATE): 1 setprio, 2 stagger
+    if ((p.ablate & 2) && (((blockIdx.x >> 3) / 32) & 1)) {   // de-phase the second block of each CU by ~half a tap
+        for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int G = (c_end - c_begin) * kt;           // halo groups: (chunk, it)
     const int S = G * 9;                            // taps
 
@@ -216,6 +327,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             read_frags(0, IC<0>{});
             read_frags(1, IC<1>{});
             __builtin_amdgcn_sched_barrier(0);
+            // the two blocks of a CU run identical timelines; raising this wave's priority while it feeds the
+            // matrix pipe lets the partner wave fall behind into its LDS / load phase (role split, guide T5)
+            if (prio) __builtin_amdgcn_s_setprio(1);
             mma_frags(IC<0>{});
             read_frags(2, IC<0>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -224,6 +338,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             __builtin_amdgcn_sched_barrier(0);
             mma_frags(IC<0>{});
             mma_frags(IC<1>{});
+            if (prio) __builtin_amdgcn_s_setprio(0);
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
             if constexpr (!GLW) {
 #pragma unroll
@@ -259,6 +374,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         const int ph = pp / TW, pw = pp % TW;
         const bool ok = (h0 + ph) < H && (w0 + pw) < W;
         mrow[bb] = ok ? ((((int64_t)b * T + t) * H + (h0 + ph)) * W + (w0 + pw)) : p.M;
+    }
+    if constexpr (std::is_same<E, BF16>::value) {
+        if (p.wp2) {       // mv2_conv_pw: fused pointwise second stage (host guarantees one co tile, no split-K)
+            const int64_t frame_row0 = ((int64_t)b * T + t) * H;
+            fused_pointwise_epilogue<BCO, BPOS, WCO, WPOS, NT>(p, smem, acc, wco, wpos, tid, [&](int lp) {
+                const int ph = lp / TW, pw = lp - ph * TW;
+                const bool ok = (h0 + ph) < H && (w0 + pw) < W;
+                return ok ? (frame_row0 + (h0 + ph)) * W + (w0 + pw) : p.M;
+            });
+            return;
+        }
     }
     if (p.splitk > 1) {
 #pragma unroll
@@ -304,7 +430,11 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
     constexpr size_t lds_main = (DBH ? 2 : 1) * halo_bytes + 2 * (size_t)BCO * 128;
     constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, TH * TW>::kBytes;
-    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    // fused pointwise stage (bf16, one co tile): stage-1 tile + C x C weights
+    constexpr size_t lds_pw = std::is_same<E, BF16>::value && BCO <= 128
+                                  ? ((size_t)StageCfg<BF16, BCO, TH * TW>::kBytes + 255) / 256 * 256 + (size_t)(BCO * 2 / 128) * BCO * 128 : 0;
+    constexpr size_t lds_a = lds_main > lds_epi ? lds_main : lds_epi;
+    constexpr size_t lds = lds_a > lds_pw ? lds_a : lds_pw;
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {

@@ -37,6 +37,9 @@ _SIGS = {
     'mv2_conv_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_conv_pw_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
+    'mv2_conv_pw': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_void_p, C.c_void_p]),
     'mv2_video_to_ndhwc': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     'mv2_rms_rowscale': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_se_pool': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -134,6 +137,17 @@ class HipOps:
         keep = (desc, x, wp, segs, bias, rowscale, residual, out, ws)
 
         return _mk(fn, args, 'mv2_conv', keep, [out, ws])
+
+    def conv_pw_eligible(self, d: dict) -> bool:
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv_pw_eligible(C.byref(desc)))
+
+    def conv_pw(self, d: dict, x, in_bytes, wp, segs, bias, wp2, bias2, act2, out):
+        desc = ConvDesc(**d)
+        fn = self.lib.mv2_conv_pw
+        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp), _ptr(segs), _ptr(bias), _ptr(wp2), _ptr(bias2), int(act2), _ptr(out))
+        keep = (desc, x, wp, segs, bias, wp2, bias2, out)
+        return _mk(fn, args, 'mv2_conv_pw', keep, [out])
 
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
         fn, args = self.lib.mv2_video_to_ndhwc, (dt, _ptr(video), _ptr(out), B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems)

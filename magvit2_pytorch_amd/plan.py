@@ -240,6 +240,22 @@ class Plan:
             self.arena.put(ws)
         return out
 
+    def _conv_pw(self, steps, pre, x: Act, k) -> Optional[Act]:
+        pm = self.pm
+        pc, pc2 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
+        d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1,
+                 sw=1, pt=k - 1, ph=k // 2, pw=k // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes,
+                 check_bounds=1, act=P.ACT_ELU, store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
+        if pc2.co != pc.co or pc2.kt != 1 or not getattr(self.ops, 'conv_pw_eligible', lambda _d: False)(d):
+            return None
+        out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
+        segs = pc.segs_tensor(x.H, x.W, x.C, self.ops.device)
+        steps.append(self.ops.conv_pw(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, segs, pc.bias, pc2.wp, pc2.bias, P.ACT_ELU, out.t))
+        steps[-1].label = pre + '.k3+k1'
+        self.step_flops[id(steps[-1])] = 2.0 * x.rows * pc.co_real * pc.k_real + 2.0 * x.rows * pc2.co_real * pc2.k_real
+        self.step_names.append(pre + '.k3+k1')
+        return out
+
     def _rms(self, steps, x: Act, shift: bool):
         rs = self.arena.get(x.rows, torch.float32)
         steps.append(self.ops.rms_rowscale(self.dt, x.t, rs, x.rows, x.C, x.H * x.W if shift else 0, x.T))
@@ -249,9 +265,11 @@ class Plan:
     def _residual_unit(self, steps, pre, x: Act) -> Act:
         pm, ops = self.pm, self.ops
         k = self.cfg['residual_conv_kernel_size']
-        y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
-        y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
-        self.arena.put(y1.t)
+        y2 = self._conv_pw(steps, pre, x, k)          # fused conv3 + ELU + conv1 + ELU where the ABI offers it (bf16, C <= 128)
+        if y2 is None:
+            y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
+            y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
+            self.arena.put(y1.t)
         frames, Pn, C = x.B * x.T, x.H * x.W, x.C
         nchunk = max(1, min(Pn // 16 if Pn >= 16 else 1, -(-1024 // frames)))   # ~1024 blocks, >= 16 rows per chunk
         part = self.arena.get(frames * nchunk * (C + 2), torch.float32)

@@ -139,6 +139,37 @@ class CpuOps:
         step.what = 'conv'
         return step
 
+    def conv_pw_eligible(self, d):
+        # mirrors mv2_conv_pw_eligible() so the CPU plan has the same launch sequence as the HIP plan
+        import os
+        if os.environ.get('MV2_NO_FUSE_PW') or os.environ.get('MV2_NO_HALO'):
+            return False
+        es = 2 if d['dtype'] == 0 else 4
+        return (d['dtype'] == 0 and d['kh'] == 3 and d['kw'] == 3 and d['st'] == d['sh'] == d['sw'] == 1 and d['ph'] == d['pw'] == 1
+                and d['pt'] == d['kt'] - 1 and d['kt'] <= 3 and d['check_bounds'] and d['seg_bytes'] == 128 and (d['Ci'] * es) % 128 == 0
+                and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['nsteps'] == d['kt'] * 9 * ((d['Ci'] * es) // 128)
+                and d['co'] in (64, 128) and d['store'] == STORE_ROWS and d['out_c'] == d['co'] and d['act'] != ACT_GEGLU)
+
+    def conv_pw(self, d, x, in_bytes, wp, segs, bias, wp2, bias2, act2, out):
+        """fused 3x3 conv + act, then 1x1x1 conv + act2 (include/mv2.h mv2_conv_pw): the intermediate is rounded
+        to the storage dtype exactly like the kernel's LDS tile."""
+        M = d['B'] * d['To'] * d['Ho'] * d['Wo']
+        co = d['co']
+        mid = torch.full((M * co,), float('nan'), dtype=x.dtype)
+        first = self.conv(d, x, in_bytes, wp, segs, bias, None, None, mid, None)
+        es = x.element_size()
+        d2 = dict(d, Ti=d['To'], Hi=d['Ho'], Wi=d['Wo'], Ci=co, kt=1, kh=1, kw=1, pt=0, ph=0, pw=0, nsteps=co * es // 128,
+                  seg_bytes=128, check_bounds=0, act=act2)
+        segs2 = torch.tensor([[j * (128 // es), (1 << 0) | (1 << 8) | (1 << 16)] for j in range(co * es // 128)], dtype=torch.int32)
+        second = self.conv(d2, mid, mid.numel() * es, wp2, segs2, bias2, None, None, out, None)
+
+        def step(stream):
+            first(stream)
+            second(stream)
+        step.outs = [out]
+        step.what = 'conv_pw'
+        return step
+
     # ------------------------------------------------------------------ layout edge
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
         def step(stream):
