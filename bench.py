@@ -123,7 +123,7 @@ def main():
     # moment later).  Not part of the W warm-up steps' semantics, never timed.
     torch.cuda.synchronize(dev)
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.5:
+    while time.perf_counter() - t_spin < (0.0 if os.environ.get('MV2_BENCH_NO_SPIN') else 0.5):
         for _ in range(5):
             step()
         torch.cuda.synchronize(dev)
@@ -169,8 +169,17 @@ def main():
     k3_flops = sum(r['flops'] for r in k3)
     achieved = k3_flops / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
     all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes (own --pmc runs, FETCH_SIZE x2
+    # correction for wide coalesced reads on gfx950, see profiles/README.md) - not collectable inside this process
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if os.path.exists(tf) and args.dtype == 'bf16' and B == 1:
+        try:
+            traffic = json.load(open(tf)).get('conv_halo_kernel_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
     roofline = dict(bound='mfma', kernel='conv_halo_kernel (ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
-                    achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=None,
+                    achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
                     launches=len(k3), flops_per_launch=k3_flops / max(len(k3), 1), avg_launch_ms=round(k3_ms / max(len(k3), 1), 5),
                     all_conv_launches=dict(launches=len(conv), flops_per_step=conv_flops, ms_per_step=round(conv_ms, 4),
                                            achieved=round(all_conv, 2), frac=round(all_conv / peak, 4)),
