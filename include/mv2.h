@@ -158,6 +158,19 @@ int mv2_se_gate(const float* part, const float* w1t, const float* b1, const floa
 int mv2_se_apply(int dtype, const void* y, const float* gate, const void* residual, void* out, int frames,
                  int P, int C, void* stream);
 
+/* Two-launch form of the same SqueezeExcite for frames small enough to be pooled by one workgroup
+ * (the caller uses it when a frame's P*C elements are <= 512 KB); results equal pool+gate+apply.
+ *   pool_fc1 : grid (nslice, frames): whole-frame softmax pooling + hidden/nslice units of
+ *              hid[f][k] = lrelu_0.1(W1 pooled + b1)            (hidden % nslice == 0, hidden/nslice a power of 2)
+ *   fc2_apply: grid (nslice, frames): gate = sigmoid(W2 hid + b2) for C/nslice channels (a power of 2),
+ *              out = gate * y + residual for those channels of every position of the frame.
+ */
+int mv2_se_pool_fc1(int dtype, const void* y, const float* wk, float bk, const float* w1t, const float* b1,
+                    float* hid, int frames, int P, int C, int hidden, int nslice, void* stream);
+int mv2_se_fc2_apply(int dtype, const void* y, const float* hid, const float* w2t, const float* b2,
+                     const void* residual, void* out, int frames, int P, int C, int hidden, int nslice,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * mv2_attention — softmax attention with learned memory key/values.
  * Replaces: Attention.forward M:381-387 (split heads, prepend mem_kv) + Attend.forward A:186-243

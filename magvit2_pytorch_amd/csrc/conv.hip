@@ -43,28 +43,37 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int s_begin = z * p.steps_per_split;
     const int s_end = min(d.nsteps, s_begin + p.steps_per_split);
 
-    // ---- per-thread gather state for its RP position rows
+    // ---- gather state of the block's BPOS position rows: {byte offset of the tap origin (mod 2^32), tap-validity
+    // mask}.  Each row is decoded ONCE (one thread per row, 32-bit divisions, closed-form masks) and shared through
+    // LDS: the eight lanes of a row used to repeat three 64-bit divisions for each of their RP rows, which was a
+    // ~1200-instruction prologue -- most of the fixed ~15 us floor of the small launches.
     uint32_t rowbase[RP], rowmask[RP];
-#pragma unroll
-    for (int i = 0; i < RP; ++i) {
-        const int64_t m = m0 + r0 + 32 * i;
-        rowbase[i] = 0; rowmask[i] = 0;
-        if (m < p.M) {
-            const int wo = (int)(m % d.Wo); int64_t r = m / d.Wo;
-            const int ho = (int)(r % d.Ho); r /= d.Ho;
-            const int to = (int)(r % d.To); const int b = (int)(r / d.To);
-            const int t_in = to * d.st - d.pt, h_in = ho * d.sh - d.ph, w_in = wo * d.sw - d.pw;
-            const int64_t base = ((((int64_t)b * d.Ti + t_in) * d.Hi + h_in) * d.Wi + w_in) * (int64_t)d.Ci;
-            rowbase[i] = (uint32_t)(base * E::kBytes);
-            uint32_t mk = 0x00ffffffu;
-            if (d.check_bounds) {
-                mk = 0;
-                for (int k = 0; k < d.kt; ++k) if ((unsigned)(t_in + k) < (unsigned)d.Ti) mk |= 1u << k;
-                for (int k = 0; k < d.kh; ++k) if ((unsigned)(h_in + k) < (unsigned)d.Hi) mk |= 1u << (8 + k);
-                for (int k = 0; k < d.kw; ++k) if ((unsigned)(w_in + k) < (unsigned)d.Wi) mk |= 1u << (16 + k);
+    {
+        uint32_t* tab = (uint32_t*)smem;        // [BPOS][2]; LDS is idle before the K loop
+        for (int r = tid; r < BPOS; r += 256) {
+            const int64_t m = m0 + r;
+            uint32_t base = 0, mk = 0;
+            if (m < p.M) {
+                int b, to, ho, wo; decode_pos<E>(d, m, b, to, ho, wo);
+                const int t_in = to * d.st - d.pt, h_in = ho * d.sh - d.ph, w_in = wo * d.sw - d.pw;
+                // wrapping 32-bit arithmetic: base + tap offset is a true offset < in_bytes < 2^32 whenever the tap is valid
+                base = ((((uint32_t)b * (uint32_t)d.Ti + (uint32_t)t_in) * (uint32_t)d.Hi + (uint32_t)h_in) * (uint32_t)d.Wi +
+                        (uint32_t)w_in) * (uint32_t)d.Ci * (uint32_t)E::kBytes;
+                mk = 0x00ffffffu;
+                if (d.check_bounds) {
+                    auto span = [](int in0, int k, int n) -> uint32_t {    // bits j in [0, k) with 0 <= in0 + j < n
+                        const int lo = max(0, -in0), hi_ = min(k, n - in0);
+                        return hi_ > lo ? (((1u << hi_) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    };
+                    mk = span(t_in, d.kt, d.Ti) | (span(h_in, d.kh, d.Hi) << 8) | (span(w_in, d.kw, d.Wi) << 16);
+                }
             }
-            rowmask[i] = mk;
+            tab[2 * r] = base; tab[2 * r + 1] = mk;
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RP; ++i) { rowbase[i] = tab[2 * (r0 + 32 * i)]; rowmask[i] = tab[2 * (r0 + 32 * i) + 1]; }
+        __syncthreads();
     }
     const int lg = p.lg_seg_chunks;
     const int seg_sub = c >> lg;
@@ -242,8 +251,9 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p) {
     const bool geglu = d.act == MV2_ACT_GEGLU;
     const int groups = geglu ? (d.co / 8) : ((d.co + 3) / 4);   // 4-wide column groups per row
     const int64_t total = p.M * groups;
+    const bool small = total < (int64_t)0x7fffffff;   // 32-bit index math whenever it fits (always, in practice)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = idx / groups;
+        const int64_t m = small ? (int64_t)((uint32_t)idx / (uint32_t)groups) : idx / groups;
         const int gi = (int)(idx - m * groups);
         if (!geglu) {
             const int n = gi * 4;
@@ -273,8 +283,23 @@ namespace {
 
 struct TileCfg { int bco, bpos; };
 
+inline int device_cus();
+
 inline TileCfg pick_tile(const mv2_conv_desc& d) {
-    if (d.act == MV2_ACT_GEGLU) return d.co <= 64 ? TileCfg{64, 256} : TileCfg{128, 128};
+    // Launches whose 128x128 tiling leaves CUs idle (the deep levels at batch 1: M = 1280..5120 rows) are chains of
+    // latencies, not MFMA work.  They use 64x64 tiles (64x128 for GEGLU, which needs value and gate in one wave):
+    // 4x the blocks, a quarter of the per-block epilogue, several blocks per CU to overlap the chains.
+    // Measured at C = 512: 1x1x1 conv 19 -> 9-12 us, to_out 13.5 -> 6.8 us.  MV2_SMALL_TILE=0 disables, =2 widens
+    // the rule to launches with fewer than 2 x CUs blocks.
+    static const int small_policy = getenv("MV2_SMALL_TILE") ? atoi(getenv("MV2_SMALL_TILE")) : 1;
+    const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
+    const int64_t blocks128 = ((d.co + 127) / 128) * ((M + 127) / 128);
+    const bool small = small_policy > 0 && d.co >= 64 && blocks128 < (int64_t)(small_policy >= 2 ? 2 : 1) * device_cus();
+    if (d.act == MV2_ACT_GEGLU) {
+        if (d.co <= 64) return {64, 256};
+        return small ? TileCfg{64, 128} : TileCfg{128, 128};
+    }
+    if (small) return {64, 64};
     if (d.co <= 32) return {32, 256};
     if (d.co <= 64) return {64, 256};
     return {128, 128};
@@ -303,8 +328,8 @@ inline bool halo_eligible(const mv2_conv_desc& d) {
            d.act != MV2_ACT_GEGLU && d.co >= 64;
 }
 
-int g_cus = 0;
 inline int device_cus() {
+    static int g_cus = 0;
     if (g_cus > 0) return g_cus;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
@@ -352,6 +377,11 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
             const int cus = device_cus();
             const int64_t slots = (int64_t)cus * slots_per_cu;
             if (blocks * 4 < slots * 3) sk = (int)((slots + blocks - 1) / blocks);
+            // ... but when two or more splits FIT one wave of block slots, take the largest that fits instead of
+            // spilling a 25 %-full second wave (C = 512, T = 20: 3 x 160 = 480 blocks, measured 102 -> 97 us;
+            // C = 256 stays at 2 x 320: one split per tile was slower, 105 -> 111 us).  MV2_HALO_SK=0: old rule.
+            static const int sk_policy = getenv("MV2_HALO_SK") ? atoi(getenv("MV2_HALO_SK")) : 1;
+            if (sk_policy == 1 && slots / blocks >= 2) sk = (int)(slots / blocks);
         }
         if (sk > L.nchunk) sk = L.nchunk;
         if (sk < 1) sk = 1;
@@ -407,6 +437,8 @@ template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
     if (L.halo) rc = mv2_launch_halo(p, L.t.bco, L.th, L.tw, st);
+    else if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1>(p, L, st);
+    else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1>(p, L, st);
     else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
     else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2>(p, L, st);
     else rc = launch_cfg<E, 32, 256, 1, 2>(p, L, st);
@@ -438,6 +470,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     int rc = validate(*d);
     if (rc != MV2_OK) return rc;
     if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
+    if ((int64_t)d->B * d->To * d->Ho * d->Wo >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;   // device row math is 32-bit
     const size_t w_bytes = (size_t)d->nsteps * d->co_pad * 128;
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     if (residual && (d->store != MV2_STORE_ROWS || d->act == MV2_ACT_GEGLU)) return MV2_EINVAL;
@@ -481,6 +514,7 @@ extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_byt
     if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
     if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU && act2 != MV2_ACT_SILU) return MV2_EINVAL;
     if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
+    if ((int64_t)d->B * d->To * d->Ho * d->Wo >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
     mv2_conv_desc dd = *d;
     dd.splitk = 1;                               // the fused stage needs the whole reduction in one block
     const Launch L = plan_launch(dd);

@@ -40,9 +40,13 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
 // ------------------------------------------------------------------------------- epilogue
 template <typename E>
 __device__ __forceinline__ void decode_pos(const mv2_conv_desc& d, int64_t m, int& b, int& t, int& h, int& w) {
-    w = (int)(m % d.Wo); int64_t r = m / d.Wo;
-    h = (int)(r % d.Ho); r /= d.Ho;
-    t = (int)(r % d.To); b = (int)(r / d.To);
+    // 32-bit on purpose: the host rejects M >= 2^31, and 64-bit integer division is a ~100-instruction
+    // emulation that dominated the prologue / shuffle epilogue of the small launches
+    uint32_t r = (uint32_t)m;
+    const uint32_t Wo = (uint32_t)d.Wo, Ho = (uint32_t)d.Ho, To = (uint32_t)d.To;
+    uint32_t q = r / Wo; w = (int)(r - q * Wo); r = q;
+    q = r / Ho; h = (int)(r - q * Ho); r = q;
+    q = r / To; t = (int)(r - q * To); b = (int)q;
 }
 
 // v[4]: raw accumulators of 4 consecutive packed columns n..n+3 of position row m
@@ -116,7 +120,8 @@ __device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int n
 template <typename E, int BCO, int BPOS>
 struct StageCfg {
     static constexpr int kPitch = BCO * E::kBytes + 16;            // bytes per staged row (pad: bank spread)
-    static constexpr int kBytes = BPOS * kPitch;
+    static constexpr int kTile = BPOS * kPitch;
+    static constexpr int kBytes = kTile + BPOS * 8;                // + destination-row table (int64 per staged row)
 };
 
 template <typename E> __device__ __forceinline__ void lds_put4(char* dst, const float* v);
@@ -143,12 +148,26 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
     constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const bool geglu = d.act == MV2_ACT_GEGLU;
+    // destination row of every staged row (-1: outside the tensor), decoded once per row here so that phase 2
+    // has no division left (the depth-to-space store used to decode b,t,h,w per 16-byte chunk)
+    int64_t* rowtab = (int64_t*)(lds + StageCfg<E, BCO, BPOS>::kTile);
     // ---- phase 1: finish values per lane, write the tile
 #pragma unroll
     for (int b = 0; b < WPOS; ++b) {
         const int lp = wpos * 32 * WPOS + b * 32 + l31;
         const int64_t m = row_of(lp);
         const bool valid = m < p.M;
+        if (wco == 0 && hi == 0) {
+            int64_t dr = -1;
+            if (valid) {
+                dr = m;
+                if (d.store == MV2_STORE_SHUFFLE) {
+                    int b_, t_, h_, w_; decode_pos<E>(d, m, b_, t_, h_, w_);
+                    dr = (((int64_t)b_ * (d.To * d.rt) + t_ * d.rt) * (d.Ho * d.rh) + h_ * d.rh) * (int64_t)(d.Wo * d.rw) + w_ * d.rw;
+                }
+            }
+            rowtab[lp] = dr;
+        }
         const float rs = (valid && p.rowscale) ? p.rowscale[m] : 1.f;
         char* rowp = lds + lp * PITCH;
         if (geglu) {
@@ -193,31 +212,32 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
         }
     }
     __syncthreads();
-    // ---- phase 2: coalesced 16-byte stores of whole rows
-    const int width = geglu ? BCO / 2 : BCO;                      // staged channels per row
+    // ---- phase 2: coalesced 16-byte stores of whole rows.  The chunk count per row is a power of two that
+    // divides the thread count, so a thread keeps ONE channel chunk and walks rows: everything that depends on
+    // the channel (incl. the depth-to-space sub-position) is computed once, outside the loop.
+    constexpr int CPR_FULL = BCO * E::kBytes / 16;                 // 16-byte chunks per staged row (power of two)
+    static_assert((CPR_FULL & (CPR_FULL - 1)) == 0 && NT % CPR_FULL == 0, "chunk-per-thread mapping");
+    const int cpr = geglu ? CPR_FULL / 2 : CPR_FULL;
     const int nbase = geglu ? n0 / 2 : n0;
     const int nvalid = geglu ? d.out_c : d.co;                    // valid output columns
-    const int cpr = width * E::kBytes / 16;
-    const int total = BPOS * cpr;
-    for (int q = tid; q < total; q += NT) {
-        const int lp = q / cpr, ch = q - lp * cpr;
-        const int n = nbase + ch * E::kVec;
-        if (n >= nvalid) continue;
-        const int64_t m = row_of(lp);
-        if (m >= p.M) continue;
+    const int ch = tid & (cpr - 1);
+    const int lp0 = geglu ? tid / (CPR_FULL / 2) : tid / CPR_FULL;
+    const int lstep = geglu ? NT / (CPR_FULL / 2) : NT / CPR_FULL;
+    const int n = nbase + ch * E::kVec;
+    if (n >= nvalid) return;
+    int64_t coloff = n, rowmul = d.out_c;
+    if (d.store == MV2_STORE_SHUFFLE) {
+        const uint32_t cq = (uint32_t)d.out_c;
+        const uint32_t qq = (uint32_t)n / cq, c = (uint32_t)n - qq * cq;
+        const uint32_t qw = qq % (uint32_t)d.rw, qh = (qq / (uint32_t)d.rw) % (uint32_t)d.rh, qt = qq / (uint32_t)(d.rw * d.rh);
+        coloff = (((int64_t)qt * (d.Ho * d.rh) + qh) * (int64_t)(d.Wo * d.rw) + qw) * cq + c;
+        rowmul = cq;
+    }
+    for (int lp = lp0; lp < BPOS; lp += lstep) {
+        const int64_t dr = rowtab[lp];
+        if (dr < 0) continue;
         const i32x4 val = *(const i32x4*)(lds + lp * PITCH + ch * 16);
-        int64_t dst;
-        if (d.store == MV2_STORE_SHUFFLE) {
-            int b_, t_, h_, w_; decode_pos<E>(d, m, b_, t_, h_, w_);
-            const int cq = d.out_c;
-            const int qq = n / cq, c = n - qq * cq;
-            const int qw = qq % d.rw, qh = (qq / d.rw) % d.rh, qt = qq / (d.rw * d.rh);
-            const int64_t orow = (((int64_t)b_ * (d.To * d.rt) + (t_ * d.rt + qt)) * (d.Ho * d.rh) + (h_ * d.rh + qh)) * (d.Wo * d.rw) + (w_ * d.rw + qw);
-            dst = orow * cq + c;
-        } else {
-            dst = m * d.out_c + n;
-        }
-        *(i32x4*)((char*)p.out + dst * E::kBytes) = val;
+        *(i32x4*)((char*)p.out + (dr * rowmul + coloff) * E::kBytes) = val;
     }
 }
 

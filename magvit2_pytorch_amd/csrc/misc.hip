@@ -91,6 +91,67 @@ extern "C" int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64
     return MV2_OK;
 }
 
+// --------------------------------------------------------------------------- SqueezeExcite: pooling loop
+// Online-softmax pooling of rows p_begin + slot, + R, ... < p_end of one frame by a group of G lanes (lane l owns
+// channel chunks l + v*G).  U rows per trip: the U row loads are in flight together and the running state is
+// rescaled once per trip (a one-row-per-trip loop is a chain of L2 latencies: measured 24 us for 16 trips).
+template <typename E, int NV>
+__device__ __forceinline__ void se_pool_rows(const char* __restrict__ base, int C, int G, int l, int p_begin, int p_end, int R,
+                                             const float (&wreg)[NV][E::kVec], float bk, float& m_run, float& s_run,
+                                             float (&acc)[NV][E::kVec]) {
+    constexpr int KV = E::kVec;
+    constexpr int U = 4;
+    for (int p0 = p_begin; p0 < p_end; p0 += U * R) {
+        i32x4 q[U][NV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = min(p0 + u * R, p_end - 1);       // clamped duplicate rows are masked below
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                q[u][v] = *(const i32x4*)(base + ((int64_t)p * C + (int64_t)(l + v * G) * KV) * E::kBytes);
+        }
+        float dot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dot[u] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float xv[KV];
+                Chunk<E>::unpack(q[u][v], xv);
+#pragma unroll
+                for (int k = 0; k < KV; ++k) dot[u] += xv[k] * wreg[v][k];
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < U; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+        float m_new = m_run;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dot[u] = (p0 + u * R < p_end) ? dot[u] + bk : -INFINITY;
+            m_new = fmaxf(m_new, dot[u]);
+        }
+        const float sc = expf(m_run - m_new);               // exp(-inf) = 0 on the first trip (row p0 is always valid)
+        float e[U];
+        s_run *= sc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { e[u] = expf(dot[u] - m_new); s_run += e[u]; }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) acc[v][k] *= sc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float xv[KV];
+                Chunk<E>::unpack(q[u][v], xv);
+#pragma unroll
+                for (int k = 0; k < KV; ++k) acc[v][k] += e[u] * xv[k];
+            }
+        }
+        m_run = m_new;
+    }
+}
+
 // --------------------------------------------------------------------------- SqueezeExcite: pool
 // grid (nchunk, frames).  A block streams its slice of the frame's P rows once; each row slot keeps
 // an online-softmax state (running max, sum of exp, exp-weighted channel sums) in registers; the
@@ -120,28 +181,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const void* __restrict__ y
         for (int k = 0; k < KV; ++k) acc[v][k] = 0.f;
 
     const char* base = (const char*)y + ((int64_t)f * P) * C * E::kBytes;
-    for (int p = p_begin + slot; p < p_end; p += R) {
-        float xv[NV][KV];
-        float dot = 0.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const i32x4 q = *(const i32x4*)(base + ((int64_t)p * C + (int64_t)(l + v * G) * KV) * E::kBytes);
-            Chunk<E>::unpack(q, xv[v]);
-#pragma unroll
-            for (int k = 0; k < KV; ++k) dot += xv[v][k] * wreg[v][k];
-        }
-        for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        const float logit = dot + bk;
-        const float m_new = fmaxf(m_run, logit);
-        const float sc = expf(m_run - m_new);      // exp(-inf) = 0 on the first row
-        const float e = expf(logit - m_new);
-        s_run = s_run * sc + e;
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int k = 0; k < KV; ++k) acc[v][k] = acc[v][k] * sc + e * xv[v][k];
-        m_run = m_new;
-    }
+    se_pool_rows<E, NV>(base, C, G, l, p_begin + slot, p_end, R, wreg, bk, m_run, s_run, acc);
     // merge the R slots: sm[slot*(C+2)] = {m, s, acc[C]}
     float* mine = sm + slot * (C + 2);
     if (l == 0) { mine[0] = m_run; mine[1] = s_run; }
@@ -310,6 +350,179 @@ extern "C" int mv2_se_gate(const float* part, const float* w1t, const float* b1,
     return MV2_OK;
 }
 
+// --------------------------------------------------------------------------- SqueezeExcite: two-launch form
+// For frames that fit a CU's reach (P*C of a frame <= 512 KB: the 16x16 and 32x32 levels) the three launches
+// above are latency chains on 5-20 CUs (measured 27 us per ResidualUnit at C = 512).  Two wide launches
+// replace them:
+//   pool_fc1 : grid (S, frames), 1024 threads.  Every block pools its WHOLE frame (one online-softmax pass,
+//              redundant across the S slices -- the frame is L2 resident) and produces hidden/S units of
+//              lrelu(W1 pooled + b1) with the reduction split over 1024/hs thread slices.
+//   fc2_apply: grid (S2, frames), 1024 threads.  A block owns C/S2 channels: gate = sigmoid(W2 hid + b2) for
+//              them (one round of 16 loads per thread), then out = gate * y + residual over the frame.
+template <typename E, int NV>
+__global__ __launch_bounds__(1024) void se_pool_fc1_kernel(const void* __restrict__ y, const float* __restrict__ wk, float bk,
+                                                           const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                           float* __restrict__ hid, int P, int C, int G, int hidden, int hs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KV = E::kVec;
+    const int f = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    const int R = 1024 / G;
+    const int slot = tid / G, l = tid % G;
+    float wreg[NV][KV], acc[NV][KV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) { wreg[v][k] = wk[(l + v * G) * KV + k]; acc[v][k] = 0.f; }
+    float m_run = -INFINITY, s_run = 0.f;
+    const char* base = (const char*)y + ((int64_t)f * P) * C * E::kBytes;
+    se_pool_rows<E, NV>(base, C, G, l, slot, P, R, wreg, bk, m_run, s_run, acc);
+    float* mine = sm + slot * (C + 2);
+    float* wr = sm + R * (C + 2);       // R merge weights
+    float* pooled = wr + 64;            // C
+    float* slab = pooled + C;           // 1024
+    if (l == 0) { mine[0] = m_run; mine[1] = s_run; }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) mine[2 + (l + v * G) * KV + k] = acc[v][k];
+    __syncthreads();
+    float M = -INFINITY;
+    for (int r = 0; r < R; ++r) M = fmaxf(M, sm[r * (C + 2)]);
+    if (tid < R) { const float mr = sm[tid * (C + 2)]; wr[tid] = (mr == -INFINITY) ? 0.f : expf(mr - M); }
+    __syncthreads();
+    float S = 0.f;
+    for (int r = 0; r < R; ++r) S += sm[r * (C + 2) + 1] * wr[r];
+    const float inv_s = 1.f / S;
+    for (int c = tid; c < C; c += 1024) {
+        float o = 0.f;
+        for (int r = 0; r < R; ++r) o += sm[r * (C + 2) + 2 + c] * wr[r];
+        pooled[c] = o * inv_s;
+    }
+    __syncthreads();
+    // hidden units [sl*hs, (sl+1)*hs): threads (unit, reduction slice)
+    const int KS = 1024 / hs;
+    const int kl = tid % hs, cs = tid / hs, k = sl * hs + kl;
+    const int per = (C + KS - 1) / KS;
+    float a0 = 0.f, a1 = 0.f;
+    if (k < hidden) {
+        const int c0 = cs * per, c1 = min(C, c0 + per);
+        int c = c0;
+        for (; c + 16 <= c1; c += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = w1t[(int64_t)(c + u) * hidden + k];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) { a0 += w[u] * pooled[c + u]; a1 += w[u + 1] * pooled[c + u + 1]; }
+        }
+        for (; c < c1; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
+    }
+    slab[cs * hs + kl] = a0 + a1;
+    __syncthreads();
+    if (tid < hs && k < hidden) {
+        float a = b1[k];
+        for (int q = 0; q < KS; ++q) a += slab[q * hs + tid];
+        hid[(int64_t)f * hidden + k] = a > 0.f ? a : 0.1f * a;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(1024) void se_fc2_apply_kernel(const void* __restrict__ y, const float* __restrict__ hidv,
+                                                            const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                            const void* __restrict__ res, void* __restrict__ out, int P, int C,
+                                                            int hidden, int cw) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KV = E::kVec;
+    float* hs = sm;                 // hidden
+    float* slab = hs + hidden;      // 1024
+    float* g = slab + 1024;         // cw
+    const int f = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < hidden; k += 1024) hs[k] = hidv[(int64_t)f * hidden + k];
+    __syncthreads();
+    const int GS = 1024 / cw;
+    const int cl = tid % cw, ks = tid / cw, c = sl * cw + cl;
+    const int per = (hidden + GS - 1) / GS;
+    {
+        const int k0 = ks * per, k1 = min(hidden, k0 + per);
+        float a0 = 0.f, a1 = 0.f;
+        int k = k0;
+        for (; k + 16 <= k1; k += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = w2t[(int64_t)(k + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) { a0 += w[u] * hs[k + u]; a1 += w[u + 1] * hs[k + u + 1]; }
+        }
+        for (; k < k1; ++k) a0 += w2t[(int64_t)k * C + c] * hs[k];
+        slab[ks * cw + cl] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < cw) {
+        float a = b2[c];
+        for (int q = 0; q < GS; ++q) a += slab[q * cw + tid];
+        g[tid] = 1.f / (1.f + expf(-a));
+    }
+    __syncthreads();
+    const int cps = cw / KV;                         // 16-byte chunks of the slice per row (power of two)
+    const int lg = 31 - __clz(cps);
+    const int items = P << lg;
+    const int64_t row0 = (int64_t)f * P;
+    for (int i = tid; i < items; i += 1024) {
+        const int p = i >> lg, ch = i & (cps - 1);
+        const int64_t idx = ((row0 + p) * C + (int64_t)sl * cw) / KV + ch;
+        const i32x4 yv = ((const i32x4*)y)[idx];
+        float a[8], r[8];
+        Chunk<E>::unpack(yv, a);
+        if (res) { const i32x4 rv = ((const i32x4*)res)[idx]; Chunk<E>::unpack(rv, r); }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) a[k] = a[k] * g[ch * KV + k] + (res ? r[k] : 0.f);
+        ((i32x4*)out)[idx] = Chunk<E>::pack(a);
+    }
+}
+
+extern "C" int mv2_se_pool_fc1(int dtype, const void* y, const float* wk, float bk, const float* w1t, const float* b1,
+                               float* hid, int frames, int P, int C, int hidden, int nslice, void* stream) {
+    if (!y || !wk || !w1t || !b1 || !hid || frames <= 0 || P <= 0 || nslice <= 0) return MV2_EINVAL;
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (C <= 0 || C % kvec != 0 || hidden <= 0 || hidden % nslice != 0) return MV2_EINVAL;
+    const int hs = hidden / nslice;
+    if (!is_pow2(hs) || hs > 1024) return MV2_EINVAL;
+    const int nch = C / kvec;
+    const int G = nch >= 64 ? 64 : nch;
+    if (!is_pow2(G) || (nch > 64 && nch % 64 != 0)) return MV2_EINVAL;
+    const int NV = nch / G;
+    if ((NV != 1 && NV != 2 && NV != 4) || 1024 / G > 64) return MV2_EINVAL;
+    const size_t lds = ((size_t)(1024 / G) * (C + 2) + 64 + C + 1024) * sizeof(float);
+    if (lds > 64 * 1024) return MV2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nslice, (unsigned)frames);
+#define SE_PF(EE, NVV) hipLaunchKernelGGL((se_pool_fc1_kernel<EE, NVV>), grid, dim3(1024), lds, st, y, wk, bk, w1t, b1, hid, P, C, G, hidden, hs)
+    if (dtype == MV2_BF16) { if (NV == 1) SE_PF(BF16, 1); else if (NV == 2) SE_PF(BF16, 2); else SE_PF(BF16, 4); }
+    else { if (NV == 1) SE_PF(F32, 1); else if (NV == 2) SE_PF(F32, 2); else SE_PF(F32, 4); }
+#undef SE_PF
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_se_fc2_apply(int dtype, const void* y, const float* hid, const float* w2t, const float* b2,
+                                const void* residual, void* out, int frames, int P, int C, int hidden, int nslice,
+                                void* stream) {
+    if (!y || !hid || !w2t || !b2 || !out || frames <= 0 || P <= 0 || nslice <= 0) return MV2_EINVAL;
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (C <= 0 || C % nslice != 0 || hidden <= 0 || hidden > 4096) return MV2_EINVAL;
+    const int cw = C / nslice;
+    if (!is_pow2(cw) || cw > 1024 || cw < kvec) return MV2_EINVAL;
+    if ((int64_t)P * (cw / kvec) >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
+    const size_t lds = (size_t)(hidden + 1024 + cw) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nslice, (unsigned)frames);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((se_fc2_apply_kernel<BF16>), grid, dim3(1024), lds, st, y, hid, w2t, b2, residual, out, P, C, hidden, cw);
+    else hipLaunchKernelGGL((se_fc2_apply_kernel<F32>), grid, dim3(1024), lds, st, y, hid, w2t, b2, residual, out, P, C, hidden, cw);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
 // --------------------------------------------------------------------------- SqueezeExcite: apply
 template <typename E>
 __global__ __launch_bounds__(256) void se_apply_kernel(const void* __restrict__ y, const float* __restrict__ gate,
@@ -317,9 +530,10 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const void* __restrict__ 
                                                        int P, int C) {
     const int cpr = C / E::kVec;   // chunks per row
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / cpr;
+        int64_t row, f;
+        if (nchunks < (int64_t)0x7fffffff) { const uint32_t r32 = (uint32_t)i / (uint32_t)cpr; row = r32; f = r32 / (uint32_t)P; }
+        else { row = i / cpr; f = row / P; }
         const int c0 = (int)(i - row * cpr) * E::kVec;
-        const int64_t f = row / P;
         const i32x4 yv = ((const i32x4*)y)[i];
         float a[8], r[8];
         Chunk<E>::unpack(yv, a);

@@ -45,6 +45,8 @@ _SIGS = {
     'mv2_se_pool': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_se_gate': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
     'mv2_se_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_se_pool_fc1': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    'mv2_se_fc2_apply': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     'mv2_attention': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_int64, C.c_int64, C.c_void_p]),
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -173,6 +175,18 @@ class HipOps:
         fn, args = self.lib.mv2_se_apply, (dt, _ptr(y), _ptr(gate), _ptr(residual), _ptr(out), frames, Pn, Cc)
         keep = (y, gate, residual, out)
         return _mk(fn, args, 'mv2_se_apply', keep, [out])
+
+    def se_pool_fc1(self, dt, y, wk, bk, w1, b1, hid, frames, Pn, Cc, hidden, nslice):
+        fn = self.lib.mv2_se_pool_fc1
+        args = (dt, _ptr(y), _ptr(wk), float(bk), _ptr(w1), _ptr(b1), _ptr(hid), frames, Pn, Cc, hidden, nslice)
+        keep = (y, wk, w1, b1, hid)
+        return _mk(fn, args, 'mv2_se_pool_fc1', keep, [hid])
+
+    def se_fc2_apply(self, dt, y, hid, w2, b2, residual, out, frames, Pn, Cc, hidden, nslice):
+        fn = self.lib.mv2_se_fc2_apply
+        args = (dt, _ptr(y), _ptr(hid), _ptr(w2), _ptr(b2), _ptr(residual), _ptr(out), frames, Pn, Cc, hidden, nslice)
+        keep = (y, hid, w2, b2, residual, out)
+        return _mk(fn, args, 'mv2_se_fc2_apply', keep, [out])
 
     def attention(self, dt, qkv, mem_kv, out, nseq, n, heads, dim_head, n_mem, causal, seq_inner, seq_outer_stride, tok_stride):
         fn = self.lib.mv2_attention

@@ -161,6 +161,16 @@ class Act:
         return self.B * self.T * self.H * self.W
 
 
+def _se_two_launch(Pn, C, hidden, dtype) -> bool:
+    """Eligibility of mv2_se_pool_fc1 / mv2_se_fc2_apply (include/mv2.h): a frame of at most 512 KB and
+    power-of-two widths.  MV2_SE_THREE=1 forces the three-launch form (A/B timing)."""
+    if os.environ.get('MV2_SE_THREE'):
+        return False
+    es = 2 if dtype == torch.bfloat16 else 4
+    pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
+    return Pn * C * es <= 512 * 1024 and pow2(C) and pow2(hidden) and C >= 128 and hidden >= 16
+
+
 class Plan:
     def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False):
         self.pm, self.ops, self.cfg = pm, pm.ops, pm.cfg
@@ -271,6 +281,20 @@ class Plan:
             y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
             self.arena.put(y1.t)
         frames, Pn, C = x.B * x.T, x.H * x.W, x.C
+        hidden = se_hidden(C)
+        if _se_two_launch(Pn, C, hidden, self.dtype):
+            # frames small enough for one workgroup to pool: two wide launches instead of three latency chains
+            hid = self.arena.get(frames * hidden, torch.float32)
+            out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
+            s1, s2 = hidden // max(16, hidden // 4), C // max(32, C // 8)
+            steps.append(ops.se_pool_fc1(self.dt, y2.t, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']), pm.f32[pre + '.se.w1'],
+                                         pm.f32[pre + '.se.b1'], hid, frames, Pn, C, hidden, s1))
+            steps.append(ops.se_fc2_apply(self.dt, y2.t, hid, pm.f32[pre + '.se.w2'], pm.f32[pre + '.se.b2'], x.t, out.t,
+                                          frames, Pn, C, hidden, s2))
+            self.step_names += ['se_pool_fc1', 'se_fc2_apply']
+            for t in (hid, y2.t, x.t):
+                self.arena.put(t)
+            return out
         nchunk = max(1, min(Pn // 16 if Pn >= 16 else 1, -(-1024 // frames)))   # ~1024 blocks, >= 16 rows per chunk
         part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
         gate = self.arena.get(frames * C, torch.float32)

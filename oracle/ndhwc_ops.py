@@ -249,6 +249,29 @@ class CpuOps:
         step.what = 'se_apply'
         return step
 
+    def se_pool_fc1(self, dt, y, wk, bk, w1, b1, hid, frames, Pn, Cc, hidden, nslice):
+        def step(stream):
+            yr = y[: frames * Pn * Cc].reshape(frames, Pn, Cc).to(self.acc)
+            a = torch.softmax(yr @ wk.to(self.acc) + bk, dim=1)
+            pooled = torch.einsum('fp,fpc->fc', a, yr)
+            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc) + b1.to(self.acc), 0.1)
+            hid[: frames * hidden].copy_(h.reshape(-1).float())
+        step.outs = [hid]
+        step.what = 'se_pool_fc1'
+        return step
+
+    def se_fc2_apply(self, dt, y, hid, w2, b2, residual, out, frames, Pn, Cc, hidden, nslice):
+        def step(stream):
+            n = frames * Pn * Cc
+            g = torch.sigmoid(hid[: frames * hidden].reshape(frames, hidden).to(self.acc) @ w2.to(self.acc) + b2.to(self.acc))
+            o = y[:n].reshape(frames, Pn, Cc).to(self.acc) * g[:, None, :]
+            if residual is not None:
+                o = o + residual[:n].reshape(frames, Pn, Cc).to(self.acc)
+            out[:n].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [out]
+        step.what = 'se_fc2_apply'
+        return step
+
     # ------------------------------------------------------------------ attention
     def attention(self, dt, qkv, mem_kv, out, nseq, n, heads, dim_head, n_mem, causal, seq_inner, seq_outer_stride, tok_stride):
         def step(stream):
