@@ -119,10 +119,17 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
  * without writing the intermediate tensor: out = act2(W2 . act(conv(in) + bias) + bias2).
  * Only for bf16, stride 1, "same"/causal padding, C_out in {64, 128} (a block then owns every channel of its
  * positions); mv2_conv_pw_eligible() says whether a descriptor qualifies (else issue two mv2_conv calls).
- * wp2: pointwise weights packed like any 1x1x1 conv: [C/64][128][128 B].  No workspace. */
+ * wp2: pointwise weights packed like any 1x1x1 conv: [C/64][128][128 B].  No workspace.
+ * se_part (optional, with se_wk / se_bk = SqueezeExcite to_k weight (C) and bias, M:226-231): the kernel also writes
+ * the pooling partials of every spatial tile of every frame, in mv2_se_pool's record format
+ *   se_part[(frame * n + j) * (C + 2)] = {max logit, sum exp, exp-weighted channel sums[C]}
+ * with n = mv2_conv_pw_tiles(d, &th, &tw) tiles of th x tw positions per frame and j = tile_row * ceil(W/tw) +
+ * tile_col; mv2_se_gate(..., nchunk = n) then replaces the mv2_se_pool pass over the tensor. */
 int mv2_conv_pw_eligible(const mv2_conv_desc* d);
+int mv2_conv_pw_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w);
 int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
-                const float* bias, const void* wp2, const float* bias2, int act2, void* out, void* stream);
+                const float* bias, const void* wp2, const float* bias2, int act2, const float* se_wk, float se_bk,
+                float* se_part, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * mv2_video_to_ndhwc — API-edge layout change + zero padding.
@@ -207,18 +214,19 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
  *  mv2_fsq : bounded = tanh(z + shift)*half_l - offset ; r = rint(bounded); code = r / half_w;
  *            ids[c] = sum_i (r_i + half_w_i) * basis_i (int32).
  *  *_codes : ids -> codes -> W_out codes + b_out   (indices_to_codes, M:1593).
- * W_in: (cb_total, C) fp32, W_out: (C, cb_total) fp32, cb_total = cb_dim * num_codebooks <= 32.
+ * W_in: (cb_total, C) fp32 = project_in.weight as stored; w_out_t: (cb_total, C) fp32 = project_out.weight
+ * TRANSPOSED (a lane reads consecutive channels of one code dim); cb_total = cb_dim * num_codebooks <= 32.
  * ------------------------------------------------------------------------------------------- */
-int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out,
+int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
             int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
-int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out, const float* b_out, void* out,
+int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out_t, const float* b_out, void* out,
                   int64_t rows, int C, int cb_dim, int num_codebooks, float scale, void* stream);
-int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out,
+int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, const float* shift, const float* half_l, const float* offset,
             const float* half_w, const int32_t* basis, void* quantized, int32_t* ids, float* prequant,
             int64_t rows, int C, int cb_dim, int num_codebooks, void* stream);
-int mv2_fsq_codes(int dtype, const int32_t* ids, const float* w_out, const float* b_out,
+int mv2_fsq_codes(int dtype, const int32_t* ids, const float* w_out_t, const float* b_out,
                   const int32_t* levels, const float* half_w, const int32_t* basis, void* out, int64_t rows,
                   int C, int cb_dim, int num_codebooks, void* stream);
 

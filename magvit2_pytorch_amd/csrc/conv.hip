@@ -286,12 +286,12 @@ struct TileCfg { int bco, bpos; };
 inline int device_cus();
 
 inline TileCfg pick_tile(const mv2_conv_desc& d) {
-    // Launches whose 128x128 tiling leaves CUs idle (the deep levels at batch 1: M = 1280..5120 rows) are chains of
-    // latencies, not MFMA work.  They use 64x64 tiles (64x128 for GEGLU, which needs value and gate in one wave):
-    // 4x the blocks, a quarter of the per-block epilogue, several blocks per CU to overlap the chains.
-    // Measured at C = 512: 1x1x1 conv 19 -> 9-12 us, to_out 13.5 -> 6.8 us.  MV2_SMALL_TILE=0 disables, =2 widens
-    // the rule to launches with fewer than 2 x CUs blocks.
-    static const int small_policy = getenv("MV2_SMALL_TILE") ? atoi(getenv("MV2_SMALL_TILE")) : 1;
+    // Launches whose 128x128 tiling gives fewer than 2 blocks per CU (the deep levels at batch 1: M = 1280..20480
+    // rows) are chains of latencies, not MFMA work.  They use 64x64 tiles (64x128 for GEGLU, which needs value and
+    // gate in one wave): 4x the blocks, a quarter of the per-block epilogue, several blocks per CU to overlap the
+    // chains.  Measured at C = 512: 1x1x1 conv 19 -> 9-12 us, to_out 13.5 -> 6.8 us; C = 256: 20.5 -> 16 us.
+    // MV2_SMALL_TILE=0 disables, =1 restricts the rule to launches with fewer than 1 block per CU.
+    static const int small_policy = getenv("MV2_SMALL_TILE") ? atoi(getenv("MV2_SMALL_TILE")) : 2;
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     const int64_t blocks128 = ((d.co + 127) / 128) * ((M + 127) / 128);
     const bool small = small_policy > 0 && d.co >= 64 && blocks128 < (int64_t)(small_policy >= 2 ? 2 : 1) * device_cus();
@@ -480,6 +480,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.d = *d; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = rowscale; p.residual = residual;
     p.out = out; p.ws = (float*)workspace;
     p.wp2 = nullptr; p.bias2 = nullptr; p.act2 = MV2_ACT_NONE;
+    p.se_wk = nullptr; p.se_bk = 0.f; p.se_part = nullptr;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = L.M; p.lg_seg_chunks = ilog2(d->seg_bytes / 16);
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
@@ -508,9 +509,22 @@ extern "C" int mv2_conv_pw_eligible(const mv2_conv_desc* d) {
     return off ? 0 : 1;
 }
 
+extern "C" int mv2_conv_pw_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w) {
+    if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
+    mv2_conv_desc dd = *d;
+    dd.splitk = 1;
+    const Launch L = plan_launch(dd);
+    if (!L.halo) return MV2_EINVAL;
+    if (tile_h) *tile_h = L.th;
+    if (tile_w) *tile_w = L.tw;
+    return L.tiles_h * L.tiles_w;
+}
+
 extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
-                           const float* bias, const void* wp2, const float* bias2, int act2, void* out, void* stream) {
+                           const float* bias, const void* wp2, const float* bias2, int act2, const float* se_wk, float se_bk,
+                           float* se_part, void* out, void* stream) {
     if (!d || !in || !wp || !segs || !wp2 || !out) return MV2_EINVAL;
+    if (se_part && !se_wk) return MV2_EINVAL;
     if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
     if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU && act2 != MV2_ACT_SILU) return MV2_EINVAL;
     if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
@@ -523,6 +537,7 @@ extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_byt
     p.d = dd; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = nullptr; p.residual = nullptr;
     p.out = out; p.ws = nullptr;
     p.wp2 = wp2; p.bias2 = bias2; p.act2 = act2;
+    p.se_wk = se_wk; p.se_bk = se_bk; p.se_part = se_part;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)((size_t)dd.nsteps * dd.co_pad * 128);
     p.M = L.M; p.lg_seg_chunks = ilog2(dd.seg_bytes / 16);
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;

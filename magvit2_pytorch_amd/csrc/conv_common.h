@@ -32,6 +32,10 @@ struct ConvParams {
     const void* wp2;
     const float* bias2;
     int32_t act2;
+    // ... and, optionally, the SqueezeExcite pooling partials of the finished tile (mv2_conv_pw se_part)
+    const float* se_wk;
+    float se_bk;
+    float* se_part;
 };
 
 // conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice

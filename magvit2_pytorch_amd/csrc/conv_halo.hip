@@ -33,7 +33,7 @@
 // nn.ELU of ResidualUnit (reference magvit2_pytorch.py:938-940) and one full write + read of the tensor.
 template <int BCO, int BPOS, int WCO, int WPOS, int NT, typename RowFn>
 __device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int wco, int wpos,
-                                                         int tid, RowFn row_of) {
+                                                         int tid, int64_t tile_index, RowFn row_of) {
     typedef BF16 E;
     const mv2_conv_desc& d = p.d;
     constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
@@ -128,9 +128,68 @@ __device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, ch
         if (m >= p.M) continue;
         *(i32x4*)((char*)p.out + (m * d.out_c + n) * 2) = *(const i32x4*)(t1 + lp * PITCH + ch * 16);
     }
+    // ---- optional: SqueezeExcite pooling partials of this tile (reference SqueezeExcite.forward M:226-231; same
+    // record as mv2_se_pool: {max logit, sum exp, exp-weighted channel sums}), computed from the bf16 tile that is
+    // still in LDS -- saves the separate pooling pass over the tensor.  The pointwise weights are dead: scratch.
+    if (p.se_part) {
+        float* lg = (float*)w2;            // [BPOS] logits, then exp(logit - max)
+        float* red = lg + BPOS;            // [32]
+        float* slab = red + 32;            // [NT]
+        constexpr int TPR = NT / BPOS;     // threads per position row (1 or 2)
+        constexpr int CH = BCO / TPR;      // channels per thread
+        static_assert(NT % BPOS == 0 && (TPR == 1 || TPR == 2) && NT % BCO == 0 && CH % 8 == 0, "pooling thread map");
+        const int lane = tid & 63, wave = tid >> 6;
+        const int lp = tid / TPR, half = tid % TPR;
+        float dot = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < CH / 8; ++c8) {
+            float xv[8];
+            Chunk<E>::unpack(*(const i32x4*)(t1 + lp * PITCH + (half * CH + c8 * 8) * 2), xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dot += xv[k] * p.se_wk[half * CH + c8 * 8 + k];
+        }
+        if (TPR == 2) dot += __shfl_xor(dot, 1, 64);
+        const bool valid = row_of(lp) < p.M;
+        const float logit = valid ? dot + p.se_bk : -INFINITY;
+        const float mx = wave_max(logit);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        float M = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) M = fmaxf(M, red[w]);
+        const float e = (valid && half == 0) ? expf(logit - M) : 0.f;     // every tile holds at least one valid row
+        if (half == 0) lg[lp] = e;
+        const float sw = wave_sum(e);
+        if (lane == 0) red[16 + wave] = sw;
+        __syncthreads();
+        constexpr int SL = NT / BCO, RPS = BPOS / SL;       // position slices x rows per slice
+        const int c = tid % BCO, sl = tid / BCO;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+        for (int r = sl * RPS; r < (sl + 1) * RPS; r += 2) {
+            a0 += lg[r] * bf2f(*(const unsigned short*)(t1 + r * PITCH + c * 2));
+            a1 += lg[r + 1] * bf2f(*(const unsigned short*)(t1 + (r + 1) * PITCH + c * 2));
+        }
+        slab[sl * BCO + c] = a0 + a1;
+        __syncthreads();
+        float* dst = p.se_part + tile_index * (BCO + 2);
+        if (tid < BCO) {
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < SL; ++q) o += slab[q * BCO + tid];
+            dst[2 + tid] = o;
+        }
+        if (tid == 0) {
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) S += red[16 + w];
+            dst[0] = M; dst[1] = S;
+        }
+    }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW>
+// WD: weight prefetch depth in taps (register sets): the weight tile of tap s + WD is requested at the top of tap s
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
     constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
@@ -221,7 +280,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
 
     i32x4 hreg[NH];
-    i32x4 wreg[2][GLW ? 1 : RW];
+    static_assert(WD == 2 || WD == 3, "weight register sets");
+    i32x4 wreg[WD][GLW ? 1 : RW];
     // GLW: the weight tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
     // ds_write_b128 at ~79 B/clk).  The LDS image of a DMA is lane-linear (wave base + lane * 16), so the
     // chunk swizzle is applied to the SOURCE address: lane (row = tid >> 3, physical chunk = tid & 7) fetches
@@ -276,6 +336,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         } else {
             issue_w(0, IC<0>{});
             issue_w(1, IC<1>{});
+            if constexpr (WD == 3) issue_w(2, IC<2>{});
         }
         write_halo(halo0);
         if constexpr (!GLW) {
@@ -291,7 +352,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             constexpr int GP = decltype(gp_c)::value;
             const int s = g * 9 + TP;
             if constexpr (GLW) dma_w(s + 1, PAR ^ 1);   // buffer PAR^1 was last read in tap s-1 (barrier passed)
-            else issue_w(s + 2, IC<PAR>{});         // wreg[PAR] is free: W(s) went to LDS during tap s-1
+            else if constexpr (WD == 2) issue_w(s + 2, IC<PAR>{});   // wreg[PAR] is free: W(s) went to LDS during tap s-1
+            else issue_w(s + 3, IC<TP % 3>{});      // three sets: set = s % 3 = TP % 3 (9 taps per group), also free
             if (TP == 0) issue_halo(g + 1);
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap
             const char* wb = wlds + PAR * WBUF;
@@ -342,7 +404,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
             if constexpr (!GLW) {
 #pragma unroll
-                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[PAR ^ 1][i];
+                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[WD == 2 ? (PAR ^ 1) : ((TP + 1) % 3)][i];
             }
             if (DBH) {
                 if (TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
@@ -378,7 +440,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
     if constexpr (std::is_same<E, BF16>::value) {
         if (p.wp2) {       // mv2_conv_pw: fused pointwise second stage (host guarantees one co tile, no split-K)
             const int64_t frame_row0 = ((int64_t)b * T + t) * H;
-            fused_pointwise_epilogue<BCO, BPOS, WCO, WPOS, NT>(p, smem, acc, wco, wpos, tid, [&](int lp) {
+            const int64_t tile_index = (((int64_t)b * T + t) * p.tiles_h + thi) * p.tiles_w + twi;
+            fused_pointwise_epilogue<BCO, BPOS, WCO, WPOS, NT>(p, smem, acc, wco, wpos, tid, tile_index, [&](int lp) {
                 const int ph = lp / TW, pw = lp - ph * TW;
                 const bool ok = (h0 + ph) < H && (w0 + pw) < W;
                 return ok ? (frame_row0 + (h0 + ph)) * W + (w0 + pw) : p.M;
@@ -424,7 +487,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
@@ -438,13 +501,13 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW>), grid, dim3(64 * NWV), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -452,15 +515,21 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
 // tile menu: (BCO, TH x TW):  (64, 16x16) one image | (128, 8x16) two images | (64, 8x16) two images, 32co x 64pos waves
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st) {
     const bool bf = p.d.dtype == MV2_BF16;
-    if (bco == 64 && th == 16 && tw == 16)
-        return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4>(p, st);
     static const bool glw = getenv("MV2_HALO_GLDS") != nullptr;   // weight tile by LDS-DMA (A/B switch)
     if (bco == 128 && th == 8 && tw == 16 && glw)
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
     if (bco == 64 && th == 16 && tw == 16 && glw)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
+    // MV2_HALO_WDEPTH=2: two weight register sets (prefetch two taps ahead) instead of three
+    static const int wdepth = getenv("MV2_HALO_WDEPTH") ? atoi(getenv("MV2_HALO_WDEPTH")) : 3;
+    if (bco == 64 && th == 16 && tw == 16 && wdepth == 3)
+        return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, false, 3>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, false, 3>(p, st);
+    if (bco == 128 && th == 8 && tw == 16 && wdepth == 3)
+        return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, false, 3>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, false, 3>(p, st);
     if (bco == 128 && th == 8 && tw == 16)
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4>(p, st);
+    if (bco == 64 && th == 16 && tw == 16)
+        return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4>(p, st);
     if (bco == 64 && th == 8 && tw == 16)
         return bf ? launch_one<BF16, 64, 8, 16, 1, true, 4>(p, st) : launch_one<F32, 64, 8, 16, 1, true, 4>(p, st);
     if (bco == 128 && th == 16 && tw == 16)     // 8 waves, one block per CU: weight tile staged once per 256 positions

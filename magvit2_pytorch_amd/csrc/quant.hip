@@ -36,21 +36,30 @@ __device__ __forceinline__ void project_in(const QuantParams& p, int64_t row, in
     for (int i = 0; i < CB_MAX; ++i) if (i < cbt) z[i] = wave_sum(z[i]) + p.b_in[i];
 }
 
-// out[c] = b_out[c] + sum_i W_out[c][i] code[i]
+// out[c] = b_out[c] + sum_i W_out[c][i] code[i].  The weight arrives TRANSPOSED, w_out_t[i][c] (cbt x C): a lane then
+// reads its kVec consecutive channels of one code dim with 16-byte loads (the (C, cbt) layout made every lane of
+// every load touch its own cache line: 80 such loads per token were most of this kernel's 32 us).
 template <typename E>
-__device__ __forceinline__ void project_out(const float* w_out, const float* b_out, void* out, int64_t row, int C, int lane,
+__device__ __forceinline__ void project_out(const float* w_out_t, const float* b_out, void* out, int64_t row, int C, int lane,
                                             int cbt, const float* code) {
     const int nch = C / E::kVec;
     for (int ch = lane; ch < nch; ch += 64) {
         float o[8];
 #pragma unroll
-        for (int k = 0; k < E::kVec; ++k) {
-            const int c = ch * E::kVec + k;
-            float a = b_out[c];
-            const float* w = w_out + (int64_t)c * cbt;
+        for (int k = 0; k < E::kVec; k += 4) {
+            const f32x4 b = *(const f32x4*)(b_out + ch * E::kVec + k);
+            o[k] = b[0]; o[k + 1] = b[1]; o[k + 2] = b[2]; o[k + 3] = b[3];
+        }
 #pragma unroll
-            for (int i = 0; i < CB_MAX; ++i) if (i < cbt) a += w[i] * code[i];
-            o[k] = a;
+        for (int i = 0; i < CB_MAX; ++i) {
+            if (i < cbt) {
+                const float* w = w_out_t + (int64_t)i * C + ch * E::kVec;
+#pragma unroll
+                for (int k = 0; k < E::kVec; k += 4) {
+                    const f32x4 wv = *(const f32x4*)(w + k);
+                    o[k] += wv[0] * code[i]; o[k + 1] += wv[1] * code[i]; o[k + 2] += wv[2] * code[i]; o[k + 3] += wv[3] * code[i];
+                }
+            }
         }
         *(i32x4*)((char*)out + (row * C + (int64_t)ch * E::kVec) * E::kBytes) = Chunk<E>::pack(o);
     }

@@ -123,7 +123,7 @@ class PackedModel:
         cbt = self.cb_dim * self.ncb
         if 'quantizers.project_in.weight' in sd:
             self.q_w_in, self.q_b_in = dev(f('quantizers.project_in.weight').contiguous()), dev(f('quantizers.project_in.bias'))
-            self.q_w_out, self.q_b_out = dev(f('quantizers.project_out.weight').contiguous()), dev(f('quantizers.project_out.bias'))
+            self.q_w_out, self.q_b_out = dev(f('quantizers.project_out.weight').t().contiguous()), dev(f('quantizers.project_out.bias'))   # (cbt, C): mv2.h w_out_t
         else:   # dim == codebook dims: identity projections
             eye = torch.eye(cbt)
             self.q_w_in, self.q_b_in, self.q_w_out, self.q_b_out = dev(eye), dev(torch.zeros(cbt)), dev(eye.clone()), dev(torch.zeros(cbt))
@@ -162,13 +162,14 @@ class Act:
 
 
 def _se_two_launch(Pn, C, hidden, dtype) -> bool:
-    """Eligibility of mv2_se_pool_fc1 / mv2_se_fc2_apply (include/mv2.h): a frame of at most 512 KB and
-    power-of-two widths.  MV2_SE_THREE=1 forces the three-launch form (A/B timing)."""
+    """Eligibility of mv2_se_pool_fc1 / mv2_se_fc2_apply (include/mv2.h): a frame of at most 256 KB (the 16x16
+    levels: measured 21.5 us against 27 us for pool + gate + apply at C = 512; at 512 KB frames the redundant
+    pooling loses, 40 us against 24 us) and power-of-two widths.  MV2_SE_THREE=1 forces the three-launch form."""
     if os.environ.get('MV2_SE_THREE'):
         return False
     es = 2 if dtype == torch.bfloat16 else 4
     pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-    return Pn * C * es <= 512 * 1024 and pow2(C) and pow2(hidden) and C >= 128 and hidden >= 16
+    return Pn * C * es <= 256 * 1024 and pow2(C) and pow2(hidden) and C >= 128 and hidden >= 16
 
 
 class Plan:
@@ -250,7 +251,7 @@ class Plan:
             self.arena.put(ws)
         return out
 
-    def _conv_pw(self, steps, pre, x: Act, k) -> Optional[Act]:
+    def _conv_pw(self, steps, pre, x: Act, k, se_part_for=None) -> Optional[Act]:
         pm = self.pm
         pc, pc2 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1,
@@ -260,7 +261,15 @@ class Plan:
             return None
         out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
         segs = pc.segs_tensor(x.H, x.W, x.C, self.ops.device)
-        steps.append(self.ops.conv_pw(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, segs, pc.bias, pc2.wp, pc2.bias, P.ACT_ELU, out.t))
+        se = {}
+        self._pw_part = None
+        if se_part_for is not None and hasattr(self.ops, 'conv_pw_tiles') and not os.environ.get('MV2_NO_FUSE_POOL'):
+            # the fused kernel also emits the SqueezeExcite pooling partials of its tiles (one record per tile)
+            n, _, _ = self.ops.conv_pw_tiles(d)
+            part = self.arena.get(x.B * x.T * n * (pc.co + 2), torch.float32)
+            se = dict(se_wk=pm.f32[se_part_for + '.se.wk'], se_bk=float(pm.f32[se_part_for + '.se.bk']), se_part=part)
+            self._pw_part = (part, n)
+        steps.append(self.ops.conv_pw(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, segs, pc.bias, pc2.wp, pc2.bias, P.ACT_ELU, out.t, **se))
         steps[-1].label = pre + '.k3+k1'
         self.step_flops[id(steps[-1])] = 2.0 * x.rows * pc.co_real * pc.k_real + 2.0 * x.rows * pc2.co_real * pc2.k_real
         self.step_names.append(pre + '.k3+k1')
@@ -275,14 +284,18 @@ class Plan:
     def _residual_unit(self, steps, pre, x: Act) -> Act:
         pm, ops = self.pm, self.ops
         k = self.cfg['residual_conv_kernel_size']
-        y2 = self._conv_pw(steps, pre, x, k)          # fused conv3 + ELU + conv1 + ELU where the ABI offers it (bf16, C <= 128)
+        frames, Pn, C = x.B * x.T, x.H * x.W, x.C
+        hidden = se_hidden(C)
+        two = _se_two_launch(Pn, C, hidden, self.dtype)
+        # fused conv3 + ELU + conv1 + ELU (+ SE pooling partials) where the ABI offers it (bf16, C <= 128)
+        self._pw_part = None
+        y2 = self._conv_pw(steps, pre, x, k, se_part_for=None if two else pre)
+        pw_part = self._pw_part
         if y2 is None:
             y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
             y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
             self.arena.put(y1.t)
-        frames, Pn, C = x.B * x.T, x.H * x.W, x.C
-        hidden = se_hidden(C)
-        if _se_two_launch(Pn, C, hidden, self.dtype):
+        if two:
             # frames small enough for one workgroup to pool: two wide launches instead of three latency chains
             hid = self.arena.get(frames * hidden, torch.float32)
             out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
@@ -295,15 +308,19 @@ class Plan:
             for t in (hid, y2.t, x.t):
                 self.arena.put(t)
             return out
-        nchunk = max(1, min(Pn // 16 if Pn >= 16 else 1, -(-1024 // frames)))   # ~1024 blocks, >= 16 rows per chunk
-        part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
         gate = self.arena.get(frames * C, torch.float32)
-        steps.append(ops.se_pool(self.dt, y2.t, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']), part, frames, Pn, C, nchunk))
+        if pw_part is not None:
+            part, nchunk = pw_part                       # written by the fused conv kernel
+        else:
+            nchunk = max(1, min(Pn // 16 if Pn >= 16 else 1, -(-1024 // frames)))   # ~1024 blocks, >= 16 rows per chunk
+            part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
+            steps.append(ops.se_pool(self.dt, y2.t, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']), part, frames, Pn, C, nchunk))
+            self.step_names.append('se_pool')
         steps.append(ops.se_gate(part, pm.f32[pre + '.se.w1'], pm.f32[pre + '.se.b1'], pm.f32[pre + '.se.w2'], pm.f32[pre + '.se.b2'],
                                  gate, frames, C, se_hidden(C), nchunk))
         out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
         steps.append(ops.se_apply(self.dt, y2.t, gate, x.t, out.t, frames, Pn, C))
-        self.step_names += ['se_pool', 'se_gate', 'se_apply']
+        self.step_names += ['se_gate', 'se_apply']
         for t in (part, gate, y2.t, x.t):
             self.arena.put(t)
         return out

@@ -150,7 +150,12 @@ class CpuOps:
                 and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['nsteps'] == d['kt'] * 9 * ((d['Ci'] * es) // 128)
                 and d['co'] in (64, 128) and d['store'] == STORE_ROWS and d['out_c'] == d['co'] and d['act'] != ACT_GEGLU)
 
-    def conv_pw(self, d, x, in_bytes, wp, segs, bias, wp2, bias2, act2, out):
+    def conv_pw_tiles(self, d):
+        # tile menu of conv_halo.hip for the fused kernel: 16x16 positions at C <= 64, 8x16 above
+        th, tw = (16, 16) if d['co'] <= 64 else (8, 16)
+        return (-(-d['Ho'] // th)) * (-(-d['Wo'] // tw)), th, tw
+
+    def conv_pw(self, d, x, in_bytes, wp, segs, bias, wp2, bias2, act2, out, se_wk=None, se_bk=0.0, se_part=None):
         """fused 3x3 conv + act, then 1x1x1 conv + act2 (include/mv2.h mv2_conv_pw): the intermediate is rounded
         to the storage dtype exactly like the kernel's LDS tile."""
         M = d['B'] * d['To'] * d['Ho'] * d['Wo']
@@ -163,10 +168,30 @@ class CpuOps:
         segs2 = torch.tensor([[j * (128 // es), (1 << 0) | (1 << 8) | (1 << 16)] for j in range(co * es // 128)], dtype=torch.int32)
         second = self.conv(d2, mid, mid.numel() * es, wp2, segs2, bias2, None, None, out, None)
 
+        def pool(stream):
+            # per-tile SqueezeExcite pooling partials from the stored (rounded) output, mv2_se_pool record format
+            n, th, tw = self.conv_pw_tiles(d)
+            B, T, H, W = d['B'], d['To'], d['Ho'], d['Wo']
+            y = out[: M * co].reshape(B * T, H, W, co).to(self.acc)
+            logits = y @ se_wk.to(self.acc) + se_bk
+            pv = se_part[: B * T * n * (co + 2)].reshape(B * T, n, co + 2)
+            j = 0
+            for h0 in range(0, H, th):
+                for w0 in range(0, W, tw):
+                    lg = logits[:, h0:h0 + th, w0:w0 + tw].reshape(B * T, -1)
+                    yy = y[:, h0:h0 + th, w0:w0 + tw].reshape(B * T, -1, co)
+                    mx = lg.max(dim=1).values
+                    e = (lg - mx[:, None]).exp()
+                    pv[:, j, 0] = mx.float(); pv[:, j, 1] = e.sum(dim=1).float()
+                    pv[:, j, 2:] = torch.einsum('fp,fpc->fc', e, yy).float()
+                    j += 1
+
         def step(stream):
             first(stream)
             second(stream)
-        step.outs = [out]
+            if se_part is not None:
+                pool(stream)
+        step.outs = [o for o in [out, se_part] if o is not None]
         step.what = 'conv_pw'
         return step
 
@@ -345,7 +370,7 @@ class CpuOps:
             if prequant is not None:
                 prequant[:rows].copy_(z.float())
             code = torch.where(z > 0, scale, -scale).to(self.acc)
-            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            o = code @ w_out.to(self.acc) + b_out.to(self.acc)
             quantized[: rows * Cc].copy_(o.reshape(-1).to(quantized.dtype))
         step.outs = [o for o in [quantized, ids, prequant] if o is not None]
         step.what = 'lfq'
@@ -356,7 +381,7 @@ class CpuOps:
             mask = (2 ** torch.arange(cb_dim - 1, -1, -1)).long()
             bits = (ids[:rows].long().reshape(rows, ncb, 1) & mask) != 0
             code = torch.where(bits, scale, -scale).to(self.acc).reshape(rows, ncb * cb_dim)
-            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            o = code @ w_out.to(self.acc) + b_out.to(self.acc)
             out[: rows * Cc].copy_(o.reshape(-1).to(out.dtype))
         step.outs = [o for o in [out] if o is not None]
         step.what = 'lfq_codes'
@@ -373,7 +398,7 @@ class CpuOps:
             ids[:rows].copy_(lvl.sum(dim=-1).to(torch.int32))
             if prequant is not None:
                 prequant[:rows].copy_(bounded.reshape(rows, -1))
-            o = code.reshape(rows, -1).to(self.acc) @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            o = code.reshape(rows, -1).to(self.acc) @ w_out.to(self.acc) + b_out.to(self.acc)
             quantized[: rows * Cc].copy_(o.reshape(-1).to(quantized.dtype))
         step.outs = [o for o in [quantized, ids, prequant] if o is not None]
         step.what = 'fsq'
@@ -383,7 +408,7 @@ class CpuOps:
         def step(stream):
             lv = (ids[:rows].reshape(rows, ncb, 1) // consts['basis']) % consts['levels']
             code = ((lv - consts['half_w']) / consts['half_w']).reshape(rows, -1).to(self.acc)
-            o = code @ w_out.to(self.acc).t() + b_out.to(self.acc)
+            o = code @ w_out.to(self.acc) + b_out.to(self.acc)
             out[: rows * Cc].copy_(o.reshape(-1).to(out.dtype))
         step.outs = [o for o in [out] if o is not None]
         step.what = 'fsq_codes'

@@ -106,6 +106,18 @@ def test_lockstep_full_channel_widths(dtype):
     run_lockstep(cfg, sd, v, dtype)
 
 
+def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
+    """Forces the pool / gate / apply form of SqueezeExcite at every level, so the pooling partials written by the
+    fused conv kernel (mv2_conv_pw se_part; several 16x16 and 8x16 tiles per frame at 32x32) and mv2_se_pool /
+    mv2_se_gate at C = 256 / 512 are all compared launch by launch."""
+    monkeypatch.setenv('MV2_SE_THREE', '1')
+    kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=9, randomize_se=True)
+    v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(10))
+    run_lockstep(cfg, sd, v, torch.bfloat16)
+
+
 def test_lockstep_conv_in_8byte_pixels(monkeypatch):
     """conv_in with 4-channel bf16 pixels (8-byte aligned 16-byte gathers): probes the cheaper layout."""
     monkeypatch.setenv('MV2_CONVIN_CPAD', '4')
