@@ -335,37 +335,25 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
-    // 4 tokens per trip: their k / v loads are in flight together (one token per trip was a latency chain)
-    constexpr int NC = 8 / E::kVec;
-    for (int t = t0; t < t1; t += 4) {
-        i32x4 kq[4][NC], vq[4][NC];
+    for (int t = t0; t < t1; ++t) {
+        const int64_t row = ((int64_t)f * n + t) * ld;
+        float k[8], v[9];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = ((int64_t)f * n + min(t + u, t1 - 1)) * ld;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                kq[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
-                vq[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
-            }
+        for (int c = 0; c < 8 / E::kVec; ++c) {
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
         }
+        v[8] = 1.f;
+        float ki = k[0];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (t + u >= t1) break;
-            float k[8], v[9];
+        for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kq[u][c], k + c * E::kVec); Chunk<E>::unpack(vq[u][c], v + c * E::kVec); }
-            v[8] = 1.f;
-            float ki = k[0];
+        for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
 #pragma unroll
-            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+        for (int jj = 0; jj < 8; ++jj) {
+            const float ph = (ki * k[jj]) * r2;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float ph = (ki * k[jj]) * r2;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
-            }
+            for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
         }
     }
     float* dst = part + (((int64_t)f * nchunk + j) * heads + h) * TAY_S;
@@ -407,62 +395,38 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
     const float scale = 0.35355339059327376220f;   // 8^-0.5
     const float r2 = 0.70710678118654752440f;
     const int tile0 = blockIdx.x * 64;
-    // TK tokens per trip share every read of the KV state from LDS (one LDS read per FMA made this kernel LDS-bound)
-    constexpr int TK = 4;
-    for (int tt0 = ts; tt0 < 64; tt0 += TK * tpb) {
-        float qv[TK][8], acc[TK][9];
-        bool live[TK];
+    for (int tt = ts; tt < 64; tt += tpb) {
+        const int t = tile0 + tt;
+        if (t >= n) break;
+        const int64_t row = (int64_t)f * n + t;
+        float qv[8];
 #pragma unroll
-        for (int u = 0; u < TK; ++u) {
-            const int tt = tt0 + u * tpb, t = tile0 + tt;
-            live[u] = tt < 64 && t < n;
-            const int64_t row = (int64_t)f * n + (live[u] ? t : tile0);
+        for (int c = 0; c < 8 / E::kVec; ++c)
+            Chunk<E>::unpack(*(const i32x4*)((const char*)q + (row * heads * 8 + h * 8) * E::kBytes + c * 16), qv + c * E::kVec);
 #pragma unroll
-            for (int c = 0; c < 8 / E::kVec; ++c)
-                Chunk<E>::unpack(*(const i32x4*)((const char*)q + (row * heads * 8 + h * 8) * E::kBytes + c * 16), qv[u] + c * E::kVec);
+        for (int d = 0; d < 8; ++d) qv[d] *= scale;
+        float acc[9];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) qv[u][d] *= scale;
-        }
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            const float s0 = S[e];                          // phi_0 = 1
-#pragma unroll
-            for (int u = 0; u < TK; ++u) acc[u][e] = s0;
-        }
+        for (int e = 0; e < 9; ++e) acc[e] = S[e];            // phi_0 = 1
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 9; ++e) {
-                const float s1 = S[(1 + i) * 9 + e];
-#pragma unroll
-                for (int u = 0; u < TK; ++u) acc[u][e] += qv[u][i] * s1;
-            }
+            for (int e = 0; e < 9; ++e) acc[e] += qv[i] * S[(1 + i) * 9 + e];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                float ph[TK];
+                const float ph = (qv[i] * qv[jj]) * r2;
 #pragma unroll
-                for (int u = 0; u < TK; ++u) ph[u] = (qv[u][i] * qv[u][jj]) * r2;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) {
-                    const float s2 = S[(9 + 8 * i + jj) * 9 + e];
-#pragma unroll
-                    for (int u = 0; u < TK; ++u) acc[u][e] += ph[u] * s2;
-                }
+                for (int e = 0; e < 9; ++e) acc[e] += ph * S[(9 + 8 * i + jj) * 9 + e];
             }
+        const float inv = 1.f / fmaxf(acc[8], 1e-5f);
+        float o[8];
 #pragma unroll
-        for (int u = 0; u < TK; ++u) {
-            if (!live[u]) continue;
-            const int64_t row = (int64_t)f * n + tile0 + tt0 + u * tpb;
-            const float inv = 1.f / fmaxf(acc[u][8], 1e-5f);
-            float o[8];
+        for (int e = 0; e < 8; ++e) o[e] = acc[e] * inv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = acc[u][e] * inv;
-#pragma unroll
-            for (int c = 0; c < 8 / E::kVec; ++c)
-                *(i32x4*)((char*)out + (row * heads * 8 + h * 8) * E::kBytes + c * 16) = Chunk<E>::pack(o + c * E::kVec);
-        }
+        for (int c = 0; c < 8 / E::kVec; ++c)
+            *(i32x4*)((char*)out + (row * heads * 8 + h * 8) * E::kBytes + c * 16) = Chunk<E>::pack(o + c * E::kVec);
     }
 }
 

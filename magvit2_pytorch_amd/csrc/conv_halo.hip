@@ -189,7 +189,8 @@ __device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, ch
 }
 
 // WD: weight prefetch depth in taps (register sets): the weight tile of tap s + WD is requested at the top of tap s
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD>
+// FD: fragment register sets per tap (2: reads of k-slice ks+2 issue after the MFMAs of ks; 4: all 16 reads first)
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD, int FD>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
     constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
@@ -345,6 +346,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
         __syncthreads();
 
+        // FD == 5: cross-tap software pipeline.  Sets 0,1 hold k-slices 0,1 of the current tap, sets 2,3 hold
+        // k-slices 2,3; the MFMAs of slices 2,3 are issued at the top of the NEXT tap (after the barrier), under
+        // that tap's first fragment reads, so every MFMA batch runs under a read batch.
+        i32x4 xw[FD == 5 ? 4 : 1][WCO], xp[FD == 5 ? 4 : 1][WPOS];
+        if constexpr (FD == 5) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int a = 0; a < WCO; ++a) xw[q][a] = i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int bb = 0; bb < WPOS; ++bb) xp[q][bb] = i32x4{0, 0, 0, 0};
+            }
+        }
         // one tap of group g: TP = tap inside the group, PAR = (g*9 + TP) & 1, GP = g & 1 — all compile-time
         auto tap = [&](int g, auto tp_c, auto par_c, auto gp_c) {
             constexpr int TP = decltype(tp_c)::value;
@@ -370,7 +384,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
                 pbase[bb] = (uint32_t)pr * 128u;
                 psw[bb] = (uint32_t)((pr >> 1) & 7);
             }
-            i32x4 fw[2][WCO], fp[2][WPOS];
+            i32x4 fw_[FD == 5 ? 1 : FD][WCO], fp_[FD == 5 ? 1 : FD][WPOS];
+            auto& fw = *[&]() { if constexpr (FD == 5) return &xw; else return &fw_; }();
+            auto& fp = *[&]() { if constexpr (FD == 5) return &xp; else return &fp_; }();
             auto read_frags = [&](int ks, auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
                 const uint32_t ck = (uint32_t)(ks * 2 + hi);
@@ -386,21 +402,36 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
 #pragma unroll
                     for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(fw[SET][a], fp[SET][bb], acc[a][bb]);
             };
-            read_frags(0, IC<0>{});
-            read_frags(1, IC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            // the two blocks of a CU run identical timelines; raising this wave's priority while it feeds the
-            // matrix pipe lets the partner wave fall behind into its LDS / load phase (role split, guide T5)
-            if (prio) __builtin_amdgcn_s_setprio(1);
-            mma_frags(IC<0>{});
-            read_frags(2, IC<0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frags(IC<1>{});
-            read_frags(3, IC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frags(IC<0>{});
-            mma_frags(IC<1>{});
-            if (prio) __builtin_amdgcn_s_setprio(0);
+            if constexpr (FD == 5) {
+                read_frags(0, IC<0>{}); read_frags(1, IC<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frags(IC<2>{}); mma_frags(IC<3>{});        // k-slices 2,3 of the PREVIOUS tap (zeros before tap 0)
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(2, IC<2>{}); read_frags(3, IC<3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frags(IC<0>{}); mma_frags(IC<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (FD == 4) {
+                read_frags(0, IC<0>{}); read_frags(1, IC<1>{}); read_frags(2, IC<2>{}); read_frags(3, IC<3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frags(IC<0>{}); mma_frags(IC<1>{}); mma_frags(IC<2>{}); mma_frags(IC<3>{});
+            } else {
+                read_frags(0, IC<0>{});
+                read_frags(1, IC<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                // the two blocks of a CU run identical timelines; raising this wave's priority while it feeds the
+                // matrix pipe lets the partner wave fall behind into its LDS / load phase (role split, guide T5)
+                if (prio) __builtin_amdgcn_s_setprio(1);
+                mma_frags(IC<0>{});
+                read_frags(2, IC<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frags(IC<1>{});
+                read_frags(3, IC<1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_frags(IC<0>{});
+                mma_frags(IC<1>{});
+                if (prio) __builtin_amdgcn_s_setprio(0);
+            }
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
             if constexpr (!GLW) {
 #pragma unroll
@@ -425,6 +456,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         int g = 0;
         for (; g + 1 < G; g += 2) { group(g, IC<0>{}); group(g + 1, IC<1>{}); }
         if (g < G) group(g, IC<0>{});
+        if constexpr (FD == 5) {       // drain: k-slices 2,3 of the last tap
+#pragma unroll
+            for (int q = 2; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(xw[q][a], xp[q][bb], acc[a][bb]);
+        }
     }
 
     // ---- epilogue (shared with conv.hip)
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2, int FD = 2>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
@@ -501,13 +540,13 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD>), grid, dim3(64 * NWV), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -520,8 +559,14 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
     if (bco == 64 && th == 16 && tw == 16 && glw)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
-    // MV2_HALO_WDEPTH=2: two weight register sets (prefetch two taps ahead) instead of three
-    static const int wdepth = getenv("MV2_HALO_WDEPTH") ? atoi(getenv("MV2_HALO_WDEPTH")) : 3;
+    // MV2_HALO_FDEPTH=4: all fragment reads of a tap before its MFMAs; =5: cross-tap pipeline (A/B switches, bf16 only)
+    static const int fdepth = getenv("MV2_HALO_FDEPTH") ? atoi(getenv("MV2_HALO_FDEPTH")) : 2;
+    if (bf && fdepth == 5 && bco == 64 && th == 16 && tw == 16) return launch_one<BF16, 64, 16, 16, 2, false, 4, false, 2, 5>(p, st);
+    if (bf && fdepth == 5 && bco == 128 && th == 8 && tw == 16) return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 5>(p, st);
+    if (bf && fdepth == 4 && bco == 64 && th == 16 && tw == 16) return launch_one<BF16, 64, 16, 16, 2, false, 4, false, 2, 4>(p, st);
+    if (bf && fdepth == 4 && bco == 128 && th == 8 && tw == 16) return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 4>(p, st);
+    // MV2_HALO_WDEPTH=3: three weight register sets (prefetch three taps ahead; measured: no gain over two)
+    static const int wdepth = getenv("MV2_HALO_WDEPTH") ? atoi(getenv("MV2_HALO_WDEPTH")) : 2;
     if (bco == 64 && th == 16 && tw == 16 && wdepth == 3)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, false, 3>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, false, 3>(p, st);
     if (bco == 128 && th == 8 && tw == 16 && wdepth == 3)
