@@ -154,3 +154,44 @@ def test_causality():
     v2[:, :, 5:] += 1.0                     # frames 5.. feed latent frames >= 2 only (time stride 4, first frame alone)
     b = tok.encode(v2)
     assert torch.equal(a[:, :, :2], b[:, :, :2]) and not torch.equal(a[:, :, 2:], b[:, :, 2:])
+
+
+# ------------------------------------------------------------------------------- SqueezeExcite lowering variants
+def _full_width_case():
+    kw = dict(image_size=16, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=7, randomize_se=True)
+    v = torch.randn(1, 3, 5, 16, 16, generator=torch.Generator().manual_seed(8))
+    return kw, cfg, sd, v
+
+
+def test_two_launch_squeeze_excite_matches_oracle():
+    """Real channel widths 64..512 on a 16x16 frame: every level with C >= 128 lowers SqueezeExcite to
+    mv2_se_pool_fc1 + mv2_se_fc2_apply; the emulated plan must still reproduce the oracle (fp32)."""
+    kw, cfg, sd, v = _full_width_case()
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    names = tok._plan(1, 5)[0].step_names
+    assert 'se_pool_fc1' in names and 'se_fc2_apply' in names
+    orc = OracleTokenizer(sd, **cfg)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    assert (codes != ocodes).float().mean().item() <= 0.005
+    assert (recon - orecon).abs().max().item() < 5e-4
+
+
+def test_squeeze_excite_forms_agree(monkeypatch):
+    """pool/gate/apply (with the pooling partials emitted by the fused conv kernel at C <= 128) against the default
+    lowering, bf16 storage: same tensors up to summation order."""
+    kw, cfg, sd, v = _full_width_case()
+    a_codes, a_recon = emulated_tokenizer(kw, sd, torch.bfloat16)(v, return_codes=True, return_recon=True)
+    monkeypatch.setenv('MV2_SE_THREE', '1')
+    tok = emulated_tokenizer(kw, sd, torch.bfloat16)
+    names = tok._plan(1, 5)[0].step_names
+    assert 'se_pool_fc1' not in names and 'se_gate' in names
+    b_codes, b_recon = tok(v, return_codes=True, return_recon=True)
+    assert (a_codes != b_codes).float().mean().item() <= 0.02
+    assert (a_recon - b_recon).abs().mean().item() < 5e-3
+    monkeypatch.setenv('MV2_NO_FUSE_POOL', '1')
+    c_codes, c_recon = emulated_tokenizer(kw, sd, torch.bfloat16)(v, return_codes=True, return_recon=True)
+    assert (b_codes != c_codes).float().mean().item() <= 0.02
+    assert (b_recon - c_recon).abs().mean().item() < 5e-3
