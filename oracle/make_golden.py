@@ -40,7 +40,12 @@ CASES = {
     # BASELINE.json configs[0] and configs[1]
     'cfg1_image128': (dict(image_size=128, init_dim=32, max_dim=512, codebook_size=512, layers=README_LAYERS), (1, 3, 128, 128), 0, 1, 2),
     'cfg2_video128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (1, 3, 17, 128, 128), 0, 1, 4),
+    # BASELINE.json configs[3] (256x256x33f; 2 of its 4 clips: clips are independent) and configs[4] (FSQ, 65 frames).
+    # These two also store the oracle's pre-sign margin so the GPU test does not have to run the CPU oracle at this size.
+    'cfg4_video256x33': (dict(image_size=256, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (2, 3, 33, 256, 256), 0, 1, 16),
+    'cfg5_fsq128x65': (dict(image_size=128, init_dim=64, max_dim=512, use_fsq=True, fsq_levels=[8, 5, 5, 5], layers=README_LAYERS), (2, 3, 65, 128, 128), 0, 1, 16),
 }
+WITH_MARGIN = ('cfg4_video256x33', 'cfg5_fsq128x65')
 
 
 def sha_tensors(tensors) -> str:
@@ -83,6 +88,16 @@ def generate(name):
         recon_abs_sum=np.float64(np.abs(r.astype(np.float64)).sum()),
         torch_version=torch.__version__,
     )
+    if name in WITH_MARGIN:
+        # min |pre-quantisation activation| per token from the restatement (which must reproduce the reference's ids)
+        from oracle.restate import OracleTokenizer
+        orc = OracleTokenizer(sd, **cfg)
+        orc.taps = {}
+        with torch.no_grad():
+            ocodes = orc.tokenize(video)
+        assert torch.equal(ocodes, codes)
+        pre = orc.taps['prequant']
+        out['margin'] = pre.abs().amin(dim=-1).reshape(codes.shape).numpy().astype(np.float32)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f'{name}.npz')
     np.savez_compressed(path, **out)

@@ -25,6 +25,8 @@ class Golden:
         self.recon_sample = torch.from_numpy(z['recon_sample'])
         self.recon_mean, self.recon_std, self.recon_abs_sum = float(z['recon_mean']), float(z['recon_std']), float(z['recon_abs_sum'])
         self._wsha, self._isha = str(z['weights_sha256']), str(z['input_sha256'])
+        # full-size cases carry the oracle's pre-sign margin per token (so a test need not re-run the CPU oracle)
+        self.margin = torch.from_numpy(z['margin']) if 'margin' in z.files else None
 
     def weights(self):
         sd = init_state_dict(self.cfg, seed=self.weight_seed, randomize_se=True)

@@ -168,6 +168,39 @@ def test_bf16_mode_within_stated_tolerance(name):
     assert derr.mean().item() <= 1.0e-2 and derr.max().item() <= 0.25
 
 
+@pytest.mark.parametrize('name', ['cfg4_video256x33', 'cfg5_fsq128x65'])
+def test_full_size_configs_vs_reference_golden(name):
+    """BASELINE configs[3] (256x256x33f: 1024-token space attention, 9-frame time attention, 4096-token linear
+    attention) and configs[4] (FSQ [8,5,5,5], 65 frames) against ids / reconstructions of the reference itself.
+    The CPU oracle is NOT run at this size: the fixture carries its pre-sign margins.  fp32 mode first (exact
+    tolerance), then bf16 mode (stated tolerance)."""
+    g = Golden(name)
+    sd = g.weights()
+    v = g.video().cuda()
+    tok = hip_tokenizer(g.kw, sd, torch.float32)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    assert codes.dtype == g.codes.dtype and codes.shape == g.codes.shape
+    diff = codes.cpu() != g.codes
+    frac = diff.float().mean().item()
+    if not g.cfg['use_fsq']:
+        assert (diff & (g.margin > 1e-4)).sum().item() == 0, 'ids differ although the oracle margin exceeds 1e-4'
+        assert frac <= 0.005, f'{frac:.4%} ids differ'
+    else:
+        assert frac <= 0.01, f'{frac:.4%} ids differ'
+    if frac == 0:
+        assert torch.allclose(g.sample(recon.cpu()), g.recon_sample, atol=5e-4, rtol=0)
+    dec = tok.decode_from_code_indices(g.codes.cuda())          # decoder alone, from the reference's ids
+    assert torch.allclose(g.sample(dec.cpu()), g.recon_sample, atol=5e-4, rtol=0)
+    del tok
+    tok = hip_tokenizer(g.kw, sd, torch.bfloat16)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    bfrac = (codes.cpu() != g.codes).float().mean().item()
+    err = (g.sample(recon.cpu()) - g.recon_sample).abs()
+    print(f'[{name}] fp32 ids mismatch {frac:.4%}; bf16 ids mismatch {bfrac:.3%}, recon mean|d| {err.mean().item():.2e}')
+    assert bfrac <= 0.05 and err.mean().item() <= 1.5e-2
+    assert torch.equal(tok.decode_from_code_indices(codes), recon)      # README round trip at full size
+
+
 # ------------------------------------------------------------------------------- size-independent properties
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_round_trip_identity_and_graph_replay(dtype):
