@@ -145,6 +145,9 @@ def main():
         # the one exchange the path has: gather ids for the global batch (off the timed path)
         allc = D.gather_codes(codes, B * world)
         assert allc.shape[0] == B * world
+        # every rank leaves the group together; rank 0 alone goes on to the per-launch profile and the JSON line
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     assert torch.isfinite(recon).all()
 
     if rank != 0:

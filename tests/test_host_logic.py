@@ -41,6 +41,46 @@ def test_library_exports_every_declared_symbol():
     ops_hip.load_library()                       # declares argtypes for all of them
 
 
+def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
+    """Error behaviour of the boundary (include/mv2.h: negative MV2_E* code, nothing thrown, nothing launched):
+    argument validation happens before any HIP call, so it can be exercised on a box without a GPU."""
+    lib = ops_hip.load_library()
+    EINVAL = -1
+    buf = ctypes.create_string_buffer(4096)
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    good = dict(dtype=0, B=1, Ti=4, Hi=16, Wi=16, Ci=64, To=4, Ho=16, Wo=16, co=64, co_pad=128, st=1, sh=1, sw=1, pt=2, ph=1, pw=1,
+                kt=3, kh=3, kw=3, nsteps=27, seg_bytes=128, check_bounds=1, act=1, store=0, rt=1, rh=1, rw=1, crop_t=0, out_c=64,
+                splitk=0)
+    d = ops_hip.ConvDesc(**good)
+    # null pointers
+    assert lib.mv2_conv(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, 0, None) == EINVAL
+    assert lib.mv2_conv_pw(ctypes.byref(d), None, 0, None, None, None, None, None, 1, None, 0.0, None, None, None) == EINVAL
+    # malformed descriptors: co_pad not a multiple of 128, unknown dtype, GEGLU with odd widths
+    for bad in (dict(co_pad=96), dict(dtype=7), dict(act=3, co=100, out_c=50), dict(seg_bytes=48), dict(kt=9)):
+        dd = ops_hip.ConvDesc(**dict(good, **bad))
+        assert lib.mv2_conv(ctypes.byref(dd), ptr, 4096, ptr, ptr, None, None, None, ptr, None, 0, None) == EINVAL, bad
+    # fused-kernel eligibility is pure host logic: bf16, C in {64, 128}, stride-1 causal 3x3 only
+    assert lib.mv2_conv_pw_eligible(ctypes.byref(d)) == 1
+    th, tw = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.mv2_conv_pw_tiles(ctypes.byref(d), ctypes.byref(th), ctypes.byref(tw)) == 1 and (th.value, tw.value) == (16, 16)
+    for bad in (dict(dtype=1), dict(co=256, co_pad=256, out_c=256, Ci=256, nsteps=108), dict(st=2)):
+        dd = ops_hip.ConvDesc(**dict(good, **bad))
+        assert lib.mv2_conv_pw_eligible(ctypes.byref(dd)) == 0, bad
+        assert lib.mv2_conv_pw_tiles(ctypes.byref(dd), None, None) == EINVAL
+    # the other entry points: null pointers / out-of-contract sizes
+    assert lib.mv2_se_pool(0, None, None, 0.0, None, 1, 1, 64, 1, None) == EINVAL
+    assert lib.mv2_se_pool(0, ptr, ptr, 0.0, ptr, 1, 4, 64, 8, None) == EINVAL                 # more chunks than rows
+    assert lib.mv2_se_gate(None, None, None, None, None, None, 1, 64, 32, 1, None) == EINVAL
+    assert lib.mv2_se_apply(0, ptr, ptr, None, ptr, 1, 4, 60, None) == EINVAL                   # C % 8 != 0 (bf16)
+    assert lib.mv2_se_pool_fc1(0, ptr, ptr, 0.0, ptr, ptr, ptr, 1, 4, 128, 64, 3, None) == EINVAL   # hidden % nslice != 0
+    assert lib.mv2_se_fc2_apply(0, ptr, ptr, ptr, ptr, None, ptr, 1, 4, 96, 48, 1, None) == EINVAL  # C/nslice not a power of 2
+    assert lib.mv2_rms_rowscale(0, None, None, 1, 64, 0, 1, None) == EINVAL
+    assert lib.mv2_attention(0, ptr, ptr, ptr, 1, 4, 8, 64, 4, 0, 1, 4, 1, None) == EINVAL      # dim_head must be 32
+    assert lib.mv2_lfq(0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, 1, 64, 17, 2, 10.0, 1.0, None) == EINVAL   # 34 code dims > 32
+    assert lib.mv2_fsq_codes(0, None, None, None, None, None, None, None, 1, 64, 4, 1, None) == EINVAL
+    assert lib.mv2_taylor_kv(0, ptr, ptr, 1, 4, 16, 8, None) == EINVAL                          # more chunks than tokens
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip('a GPU is present')
