@@ -190,7 +190,9 @@ __device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, ch
 
 // WD: weight prefetch depth in taps (register sets): the weight tile of tap s + WD is requested at the top of tap s
 // FD: fragment register sets per tap (2: reads of k-slice ks+2 issue after the MFMAs of ks; 4: all 16 reads first)
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD, int FD>
+// EW (with WD == 3): the LDS write of the next tap's weight tile is issued at the TOP of the tap (it has been in flight
+// for two taps) instead of at the end, so the write latency runs under the MFMAs and the barrier only waits for skew
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD, int FD, bool EW>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
     constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
@@ -370,6 +372,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             else issue_w(s + 3, IC<TP % 3>{});      // three sets: set = s % 3 = TP % 3 (9 taps per group), also free
             if (TP == 0) issue_halo(g + 1);
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetches at the top of the tap
+            static_assert(!EW || (WD == 3 && !GLW && FD == 2), "early weight write: third register set, FD == 2 schedule");
+            auto early_write = [&]() {
+                // buffer PAR^1 was last read in tap s-1 (all reads retired before its barrier): free to overwrite.
+                // Placed after the first MFMA batch so that a late W(s+1) stalls under running MFMAs, not before them.
+                if constexpr (EW) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[(TP + 1) % 3][i];
+                    if (DBH && TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);
+                }
+            };
             const char* wb = wlds + PAR * WBUF;
             const char* himg = halo0 + (DBH ? GP * HALO_BYTES : 0);
             constexpr int toff = (TP / 3) * HWD + (TP % 3);
@@ -424,6 +436,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
                 if (prio) __builtin_amdgcn_s_setprio(1);
                 mma_frags(IC<0>{});
                 read_frags(2, IC<0>{});
+                if constexpr (EW) early_write();
                 __builtin_amdgcn_sched_barrier(0);
                 mma_frags(IC<1>{});
                 read_frags(3, IC<1>{});
@@ -433,12 +446,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
                 if (prio) __builtin_amdgcn_s_setprio(0);
             }
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
-            if constexpr (!GLW) {
+            if constexpr (!GLW && !EW) {
 #pragma unroll
                 for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[WD == 2 ? (PAR ^ 1) : ((TP + 1) % 3)][i];
             }
             if (DBH) {
-                if (TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
+                if (!EW && TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
             } else if (TP == 8) {
                 __syncthreads();                  // every wave is done with the single halo image
                 write_halo(halo0);
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2, int FD = 2>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2, int FD = 2, bool EW = false>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
@@ -540,13 +553,13 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD>), grid, dim3(64 * NWV), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -559,6 +572,11 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
     if (bco == 64 && th == 16 && tw == 16 && glw)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
+    // MV2_HALO_EW=1: early LDS write of the next weight tile (three register sets); NOT YET MEASURED OR VALIDATED ON A GPU
+    // (written after the round-1 GPU budget was spent; next round: lockstep tests with the switch on, then A/B)
+    static const bool ew = getenv("MV2_HALO_EW") != nullptr;
+    if (bf && ew && bco == 64 && th == 16 && tw == 16) return launch_one<BF16, 64, 16, 16, 2, false, 4, false, 3, 2, true>(p, st);
+    if (bf && ew && bco == 128 && th == 8 && tw == 16) return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 3, 2, true>(p, st);
     // MV2_HALO_FDEPTH=4: all fragment reads of a tap before its MFMAs; =5: cross-tap pipeline (A/B switches, bf16 only)
     static const int fdepth = getenv("MV2_HALO_FDEPTH") ? atoi(getenv("MV2_HALO_FDEPTH")) : 2;
     if (bf && fdepth == 5 && bco == 64 && th == 16 && tw == 16) return launch_one<BF16, 64, 16, 16, 2, false, 4, false, 2, 5>(p, st);
