@@ -45,7 +45,7 @@ def _worker(rank, world, port, total, q):
     codes = D.tokenize_sharded(tok, video, gather=True)
     metrics = D.reconstruction_metrics_sharded(tok, video)
     lo, hi = D.shard_bounds(total, rank, world)
-    q.put((rank, codes, metrics, (lo, hi)))
+    q.put((rank, codes.numpy(), metrics, (lo, hi)))     # by value: a torch tensor in an mp.Queue is a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,6 +70,7 @@ def test_two_rank_sharding_matches_single_process(total):
     bounds = sorted(r[3] for r in res)
     assert bounds[0][0] == 0 and bounds[-1][1] == total and bounds[0][1] == bounds[1][0]
     for rank, codes, metrics, _ in res:
+        codes = torch.from_numpy(codes)
         assert codes.shape == ref_codes.shape and torch.equal(codes, ref_codes)
         assert abs(metrics['mse'] - ref_mse) < 1e-6 * max(1.0, ref_mse)
 
