@@ -251,7 +251,10 @@ class Plan:
             self.arena.put(ws)
         return out
 
-    def _conv_pw(self, steps, pre, x: Act, k, se_part_for=None) -> Optional[Act]:
+    def _conv_pw(self, steps, pre, x: Act, k, se_part_for=None):
+        """Fused conv3 + ELU + conv1 + ELU launch (mv2_conv_pw) if the ABI offers it for this shape, else None.
+        Returns (output, pooling partials or None); partials = (buffer, records per frame) when the kernel was also
+        asked for the SqueezeExcite pooling records of unit `se_part_for`."""
         pm = self.pm
         pc, pc2 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1,
@@ -261,19 +264,18 @@ class Plan:
             return None
         out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
         segs = pc.segs_tensor(x.H, x.W, x.C, self.ops.device)
-        se = {}
-        self._pw_part = None
+        se, pw_part = {}, None
         if se_part_for is not None and hasattr(self.ops, 'conv_pw_tiles') and not os.environ.get('MV2_NO_FUSE_POOL'):
             # the fused kernel also emits the SqueezeExcite pooling partials of its tiles (one record per tile)
             n, _, _ = self.ops.conv_pw_tiles(d)
             part = self.arena.get(x.B * x.T * n * (pc.co + 2), torch.float32)
             se = dict(se_wk=pm.f32[se_part_for + '.se.wk'], se_bk=float(pm.f32[se_part_for + '.se.bk']), se_part=part)
-            self._pw_part = (part, n)
+            pw_part = (part, n)
         steps.append(self.ops.conv_pw(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, segs, pc.bias, pc2.wp, pc2.bias, P.ACT_ELU, out.t, **se))
         steps[-1].label = pre + '.k3+k1'
         self.step_flops[id(steps[-1])] = 2.0 * x.rows * pc.co_real * pc.k_real + 2.0 * x.rows * pc2.co_real * pc2.k_real
         self.step_names.append(pre + '.k3+k1')
-        return out
+        return out, pw_part
 
     def _rms(self, steps, x: Act, shift: bool):
         rs = self.arena.get(x.rows, torch.float32)
@@ -288,9 +290,8 @@ class Plan:
         hidden = se_hidden(C)
         two = _se_two_launch(Pn, C, hidden, self.dtype)
         # fused conv3 + ELU + conv1 + ELU (+ SE pooling partials) where the ABI offers it (bf16, C <= 128)
-        self._pw_part = None
-        y2 = self._conv_pw(steps, pre, x, k, se_part_for=None if two else pre)
-        pw_part = self._pw_part
+        fused = self._conv_pw(steps, pre, x, k, se_part_for=None if two else pre)
+        y2, pw_part = fused if fused is not None else (None, None)
         if y2 is None:
             y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
             y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
