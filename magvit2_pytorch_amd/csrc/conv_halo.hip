@@ -192,7 +192,10 @@ __device__ __forceinline__ void fused_pointwise_epilogue(const ConvParams& p, ch
 // FD: fragment register sets per tap (2: reads of k-slice ks+2 issue after the MFMAs of ks; 4: all 16 reads first)
 // EW (with WD == 3): the LDS write of the next tap's weight tile is issued at the TOP of the tap (it has been in flight
 // for two taps) instead of at the end, so the write latency runs under the MFMAs and the barrier only waits for skew
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD, int FD, bool EW>
+// ABL: TIMING-ONLY ablations of one per-tap component (results are wrong; selected by MV2_HALO_ABL, never by default):
+//   1 no MFMAs (fragments still read)   2 no LDS fragment reads (MFMAs on constant registers)
+//   3 no LDS writes of weights / halo   4 no per-tap barrier   5 no global weight loads
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW, int WD, int FD, bool EW, int ABL>
 __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams p) {
     constexpr int BPOS = TH * TW;
     constexpr int NT = 64 * NWV;                   // threads: 4 waves (2 blocks / CU) or 8 waves (1 block / CU)
@@ -327,6 +330,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         const int g = s / 9, tp = s - g * 9;
         const int chunk = c_begin + g / kt, it = g % kt;
         const uint32_t wo_ = (s < S) ? w_off0 + (uint32_t)((it * 9 + tp) * p.nchunk + chunk) * w_step : p.w_bytes;
+        if constexpr (ABL == 5) {
+#pragma unroll
+            for (int i = 0; i < RW; ++i) wreg[SET][i] = i32x4{(int)wo_, 0, 0, 0};
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RW; ++i) wreg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)(i * RPP * 128)), 0, 0);
     };
@@ -402,6 +410,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             auto read_frags = [&](int ks, auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
                 const uint32_t ck = (uint32_t)(ks * 2 + hi);
+                if constexpr (ABL == 2) {       // constants instead of LDS reads
+#pragma unroll
+                    for (int a = 0; a < WCO; ++a) fw[SET][a] = i32x4{(int)ck, 0, 0, 0};
+#pragma unroll
+                    for (int bb = 0; bb < WPOS; ++bb) fp[SET][bb] = i32x4{(int)pbase[bb], 0, 0, 0};
+                    return;
+                }
 #pragma unroll
                 for (int a = 0; a < WCO; ++a) fw[SET][a] = *(const i32x4*)(wb + rd_w + a * 32 * 128 + ((ck ^ swz) << 4));
 #pragma unroll
@@ -409,6 +424,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             };
             auto mma_frags = [&](auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
+                if constexpr (ABL == 1) {       // keep the fragment reads alive, skip the matrix work
+#pragma unroll
+                    for (int a = 0; a < WCO; ++a) asm volatile("" :: "v"(fw[SET][a]));
+#pragma unroll
+                    for (int bb = 0; bb < WPOS; ++bb) asm volatile("" :: "v"(fp[SET][bb]));
+                    return;
+                }
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
@@ -447,16 +469,21 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
             }
             // W(s+1) -> the other weight buffer (after the last tap: the zero dummy into the idle buffer)
             if constexpr (!GLW && !EW) {
+                if constexpr (ABL == 3) {
 #pragma unroll
-                for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[WD == 2 ? (PAR ^ 1) : ((TP + 1) % 3)][i];
+                    for (int i = 0; i < RW; ++i) asm volatile("" :: "v"(wreg[WD == 2 ? (PAR ^ 1) : ((TP + 1) % 3)][i]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) *(i32x4*)(wlds + (PAR ^ 1) * WBUF + lds_wr + i * RPP * 128) = wreg[WD == 2 ? (PAR ^ 1) : ((TP + 1) % 3)][i];
+                }
             }
             if (DBH) {
-                if (!EW && TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
+                if (!EW && ABL != 3 && TP == HWT) write_halo(halo0 + (GP ^ 1) * HALO_BYTES);   // image of group g-1: idle since 6+ barriers
             } else if (TP == 8) {
                 __syncthreads();                  // every wave is done with the single halo image
                 write_halo(halo0);
             }
-            __syncthreads();
+            if constexpr (ABL != 4) __syncthreads();
         };
         auto group = [&](int g, auto gp_c) {
             constexpr int GP = decltype(gp_c)::value;
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv_halo_kernel(const ConvParams
         }
 }
 
-template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2, int FD = 2, bool EW = false>
+template <typename E, int BCO, int TH, int TW, int WCO, bool DBH, int NWV, bool GLW = false, int WD = 2, int FD = 2, bool EW = false, int ABL = 0>
 static int launch_one(const ConvParams& p, hipStream_t st) {
     constexpr int HR = (TH + 2) * (TW + 2);
     constexpr size_t halo_bytes = (size_t)((HR * 128 + 255) / 256) * 256;
@@ -553,13 +580,13 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
     static_assert(lds <= (NWV == 8 ? 160 : 80) * 1024, "LDS budget: two 4-wave blocks or one 8-wave block per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     dim3 grid((unsigned)(p.n_co_tiles * p.n_pos_tiles), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW>), grid, dim3(64 * NWV), lds, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<E, BCO, TH, TW, WCO, DBH, NWV, GLW, WD, FD, EW, ABL>), grid, dim3(64 * NWV), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -572,6 +599,18 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
     if (bco == 64 && th == 16 && tw == 16 && glw)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
+    // MV2_HALO_ABL=1..5: timing-only component ablations of the 128co x 8x16 bf16 kernel (results are WRONG; see the kernel header)
+    static const int abl = getenv("MV2_HALO_ABL") ? atoi(getenv("MV2_HALO_ABL")) : 0;
+    if (bf && abl && bco == 128 && th == 8 && tw == 16) {
+        switch (abl) {
+            case 1: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 1>(p, st);
+            case 2: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 2>(p, st);
+            case 3: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 3>(p, st);
+            case 4: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 4>(p, st);
+            case 5: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 5>(p, st);
+            default: break;
+        }
+    }
     // MV2_HALO_EW=1: early LDS write of the next weight tile (three register sets); NOT YET MEASURED OR VALIDATED ON A GPU
     // (written after the round-1 GPU budget was spent; next round: lockstep tests with the switch on, then A/B)
     static const bool ew = getenv("MV2_HALO_EW") != nullptr;
