@@ -600,7 +600,7 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
     if (bco == 64 && th == 16 && tw == 16 && glw)
         return bf ? launch_one<BF16, 64, 16, 16, 2, false, 4, true>(p, st) : launch_one<F32, 64, 16, 16, 2, false, 4, true>(p, st);
     // MV2_HALO_ABL=1..5: timing-only component ablations of the 128co x 8x16 bf16 kernel (results are WRONG; see the kernel header)
-    static const int abl = getenv("MV2_HALO_ABL") ? atoi(getenv("MV2_HALO_ABL")) : 0;
+    const int abl = getenv("MV2_HALO_ABL") ? atoi(getenv("MV2_HALO_ABL")) : 0;      // re-read per launch: tools/halo_ablation.py switches it in-process
     if (bf && abl && bco == 128 && th == 8 && tw == 16) {
         switch (abl) {
             case 1: return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 2, 2, false, 1>(p, st);
@@ -613,7 +613,7 @@ int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st
     }
     // MV2_HALO_EW=1: early LDS write of the next weight tile (three register sets); NOT YET MEASURED OR VALIDATED ON A GPU
     // (written after the round-1 GPU budget was spent; next round: lockstep tests with the switch on, then A/B)
-    static const bool ew = getenv("MV2_HALO_EW") != nullptr;
+    const bool ew = getenv("MV2_HALO_EW") != nullptr;
     if (bf && ew && bco == 64 && th == 16 && tw == 16) return launch_one<BF16, 64, 16, 16, 2, false, 4, false, 3, 2, true>(p, st);
     if (bf && ew && bco == 128 && th == 8 && tw == 16) return launch_one<BF16, 128, 8, 16, 2, true, 4, false, 3, 2, true>(p, st);
     // MV2_HALO_FDEPTH=4: all fragment reads of a tap before its MFMAs; =5: cross-tap pipeline (A/B switches, bf16 only)
