@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmv2_hip.so')
-SOURCES = ['conv.hip', 'conv_halo.hip', 'misc.hip', 'attn.hip', 'quant.hip']
+SOURCES = ['conv.hip', 'conv_halo.hip', 'conv_halo_rs.hip', 'misc.hip', 'attn.hip', 'quant.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 

@@ -371,6 +371,24 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
         L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
         L.n_pos_tiles = d.B * d.To * L.tiles_h * L.tiles_w;
         int sk = d.splitk;
+        // MV2_HALO_RS=1 (conv_halo_rs.hip, one 8-wave block per CU): pick the split that fills whole rounds of CUs,
+        // charging ~7 % of a launch per extra fp32 slab (write + re-read in conv_finish)
+        const bool rs = getenv("MV2_HALO_RS") != nullptr && d.dtype == MV2_BF16 && L.t.bco == 128 && L.t.bpos == 128;
+        if (sk <= 0 && rs) {
+            const int64_t tiles = (int64_t)L.n_co_tiles * L.n_pos_tiles;
+            const int cus = device_cus();
+            double best = -1.0;
+            sk = 1;
+            for (int cand = 1; cand <= L.nchunk && cand <= 8; ++cand) {
+                const int cps = (L.nchunk + cand - 1) / cand;
+                const int eff_sk = (L.nchunk + cps - 1) / cps;
+                if (eff_sk != cand) continue;
+                const int64_t blocks = tiles * eff_sk;
+                const int64_t rounds = (blocks + cus - 1) / cus;
+                const double score = (double)blocks / (double)(rounds * cus) - 0.07 * (eff_sk - 1);
+                if (score > best + 1e-9) { best = score; sk = eff_sk; }
+            }
+        }
         if (sk <= 0) {
             sk = 1;
             const int64_t blocks = (int64_t)L.n_co_tiles * L.n_pos_tiles;

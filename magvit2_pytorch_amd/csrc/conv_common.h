@@ -40,6 +40,9 @@ struct ConvParams {
 
 // conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st);
+// conv_halo_rs.hip: role-specialised 8-wave variant (MV2_HALO_RS=1 only; not yet validated on a GPU)
+bool mv2_halo_rs_eligible(const ConvParams& p, int bco, int th, int tw);
+int mv2_launch_halo_rs(const ConvParams& p, hipStream_t st);
 
 // ------------------------------------------------------------------------------- epilogue
 template <typename E>
@@ -145,9 +148,11 @@ __device__ __forceinline__ bool stage_ok(const ConvParams& p) {
     return p.d.store != MV2_STORE_NCTHW_F32 && ((p.d.out_c * es) % 16) == 0 && (p.d.co % (16 / es)) == 0;
 }
 
+// owner: false for waves that hold no accumulators (the load waves of conv_halo_rs.hip); they skip phase 1 and
+// only help with the row stores of phase 2
 template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typename RowFn>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
-                                                int wpos, int tid, RowFn row_of) {
+                                                int wpos, int tid, RowFn row_of, bool owner = true) {
     const mv2_conv_desc& d = p.d;
     constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -158,6 +163,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
     // ---- phase 1: finish values per lane, write the tile
 #pragma unroll
     for (int b = 0; b < WPOS; ++b) {
+        if (!owner) break;
         const int lp = wpos * 32 * WPOS + b * 32 + l31;
         const int64_t m = row_of(lp);
         const bool valid = m < p.M;

@@ -594,6 +594,8 @@ static int launch_one(const ConvParams& p, hipStream_t st) {
 // tile menu: (BCO, TH x TW):  (64, 16x16) one image | (128, 8x16) two images | (64, 8x16) two images, 32co x 64pos waves
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st) {
     const bool bf = p.d.dtype == MV2_BF16;
+    // MV2_HALO_RS=1: role-specialised 8-wave kernel (conv_halo_rs.hip) where it applies; NOT yet validated on a GPU
+    if (getenv("MV2_HALO_RS") != nullptr && mv2_halo_rs_eligible(p, bco, th, tw)) return mv2_launch_halo_rs(p, st);
     static const bool glw = getenv("MV2_HALO_GLDS") != nullptr;   // weight tile by LDS-DMA (A/B switch)
     if (bco == 128 && th == 8 && tw == 16 && glw)
         return bf ? launch_one<BF16, 128, 8, 16, 2, true, 4, true>(p, st) : launch_one<F32, 128, 8, 16, 2, true, 4, true>(p, st);
