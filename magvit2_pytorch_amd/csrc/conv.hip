@@ -523,8 +523,7 @@ extern "C" int mv2_conv_pw_eligible(const mv2_conv_desc* d) {
     if (d->dtype != MV2_BF16 || !halo_eligible(*d)) return 0;
     if (d->co > 128 || (d->co != 64 && d->co != 128) || d->store != MV2_STORE_ROWS || d->out_c != d->co) return 0;
     if (d->act == MV2_ACT_GEGLU) return 0;
-    static const bool off = getenv("MV2_NO_FUSE_PW") != nullptr;
-    return off ? 0 : 1;
+    return getenv("MV2_NO_FUSE_PW") != nullptr ? 0 : 1;      // read per call (plan-build time only): tests toggle it in-process
 }
 
 extern "C" int mv2_conv_pw_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w) {

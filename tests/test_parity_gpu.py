@@ -10,6 +10,8 @@ Tolerances (stated once, used below):
                drift vs its fp32 (1.6-2.2 % ids, recon mean|d| 4-7e-3, max 0.35):
                ids mismatch <= 5 %, recon mean|d| <= 1.5e-2.
 """
+import os
+
 import pytest
 import torch
 
@@ -115,6 +117,22 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     cfg = make_cfg(**kw)
     sd = init_state_dict(cfg, seed=9, randomize_se=True)
     v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(10))
+    run_lockstep(cfg, sd, v, torch.bfloat16)
+
+
+@pytest.mark.skipif(not os.environ.get('MV2_TEST_EXPERIMENTAL'),
+                    reason='kernel variants that are off by default and not validated yet: set MV2_TEST_EXPERIMENTAL=1')
+@pytest.mark.parametrize('switch', ['MV2_HALO_RS', 'MV2_HALO_EW'])
+def test_lockstep_experimental_halo_variants(switch, monkeypatch):
+    """Launch-by-launch parity of the opt-in halo-conv variants (role-specialised kernel, early weight write) on the
+    real channel widths with several tiles per frame.  Both switches are read per launch, so one process can test
+    them; nothing here runs unless MV2_TEST_EXPERIMENTAL is set."""
+    monkeypatch.setenv(switch, '1')
+    monkeypatch.setenv('MV2_NO_FUSE_PW', '1')          # the role-specialised kernel covers the non-fused launches
+    kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=11, randomize_se=True)
+    v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(12))
     run_lockstep(cfg, sd, v, torch.bfloat16)
 
 
