@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MV2_ABI_VERSION 1
+#define MV2_ABI_VERSION 2
 
 enum { MV2_BF16 = 0, MV2_F32 = 1 };
 
@@ -114,22 +114,39 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
              const float* bias, const float* rowscale, const void* residual, void* out,
              void* workspace, size_t workspace_bytes, void* stream);
 
-/* mv2_conv_pw — fused front half of a ResidualUnit (M:937-940): the kt x 3 x 3 causal convolution described by
- * `d` (+ bias, d->act), immediately followed by a 1x1x1 convolution over the same channels (+ bias2, act2),
- * without writing the intermediate tensor: out = act2(W2 . act(conv(in) + bias) + bias2).
- * Only for bf16, stride 1, "same"/causal padding, C_out in {64, 128} (a block then owns every channel of its
- * positions); mv2_conv_pw_eligible() says whether a descriptor qualifies (else issue two mv2_conv calls).
- * wp2: pointwise weights packed like any 1x1x1 conv: [C/64][128][128 B].  No workspace.
- * se_part (optional, with se_wk / se_bk = SqueezeExcite to_k weight (C) and bias, M:226-231): the kernel also writes
- * the pooling partials of every spatial tile of every frame, in mv2_se_pool's record format
- *   se_part[(frame * n + j) * (C + 2)] = {max logit, sum exp, exp-weighted channel sums[C]}
- * with n = mv2_conv_pw_tiles(d, &th, &tw) tiles of th x tw positions per frame and j = tile_row * ceil(W/tw) +
- * tile_col; mv2_se_gate(..., nchunk = n) then replaces the mv2_se_pool pass over the tensor. */
-int mv2_conv_pw_eligible(const mv2_conv_desc* d);
-int mv2_conv_pw_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w);
-int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
-                const float* bias, const void* wp2, const float* bias2, int act2, const float* se_wk, float se_bk,
-                float* se_part, void* out, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * mv2_conv3 — the ResidualUnit convolution: stride-1 kt x 3 x 3 (kt <= 3) causal-in-time / "same"-in-space
+ * CausalConv3d over whole 128-byte channel chunks, C_out >= 64.
+ * Replaces: ResidualUnit's CausalConv3d + ELU M:937-938 (F.pad M:927 + nn.Conv3d), and — when `wp2` is given —
+ * also nn.Conv3d(dim, dim, 1) + ELU M:939-940 and the softmax pooling of SqueezeExcite M:226-231 of the same
+ * unit, without writing the intermediate tensor:  out = act2(W2 . act(conv(in) + bias) + bias2).
+ *
+ * `d` describes the convolution exactly as for mv2_conv (st = sh = sw = 1, ph = pw = 1, pt = kt - 1, check_bounds = 1,
+ * nsteps = kt * 9 * C_in*esize/128); mv2_conv3_eligible() says whether a descriptor qualifies (else: mv2_conv).
+ * wp3: the same [nsteps][co_pad][128 B] weights as mv2_conv's Wp (step = ((it*3 + ih)*3 + iw) * nchunk + chunk), but each
+ *      group of 32 output rows is stored in MFMA-fragment order: [step][co_pad/32][k-slice 4][half 2][row 32][16 B],
+ *      where the 16-byte chunk (2*k-slice + half) of row r of the plain layout is meant (pack.py pack_conv3d(frag_major)).
+ * Epilogue as mv2_conv (rowscale, bias, act, residual; MV2_STORE_ROWS or MV2_STORE_SHUFFLE).
+ * Fused second stage (wp2 != NULL): bf16 only, C_out in {64, 128} (a block then owns every channel of its
+ *      positions), no rowscale / residual; wp2 = the pointwise weights packed like any 1x1x1 conv ([C/64][128][128 B]).
+ *      se_part (optional, with se_wk / se_bk = SqueezeExcite to_k weight (C) and bias): the kernel also writes the
+ *      pooling partials of every spatial tile of every frame in mv2_se_pool's record format
+ *        se_part[(frame * n + j) * (C + 2)] = {max logit, sum exp, exp-weighted channel sums[C]},
+ *      n = mv2_conv3_tiles(d, &th, &tw) tiles of th x tw positions per frame, j = tile_row * ceil(W/tw) + tile_col.
+ * Work split: one workgroup per CU walks an equal share of the (tile, chunk, time-tap) list; a tile shared by
+ *      several workgroups is combined in-kernel (fp32 partials in `workspace`, a ticket per tile in `counters`, summed
+ *      in a fixed order: results are bitwise reproducible).  workspace: mv2_conv3_workspace_bytes(d) bytes, contents
+ *      irrelevant.  counters: mv2_conv3_counter_bytes(d) bytes that MUST BE ZERO when the launch starts; the kernel
+ *      leaves them zero, so one zero-initialised buffer can serve every mv2_conv3 launch of a stream.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_conv3_eligible(const mv2_conv_desc* d);
+size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d);
+size_t mv2_conv3_counter_bytes(const mv2_conv_desc* d);
+int mv2_conv3_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w);
+int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp3, const float* bias,
+              const float* rowscale, const void* residual, const void* wp2, const float* bias2, int act2,
+              const float* se_wk, float se_bk, float* se_part, void* out, void* workspace, size_t workspace_bytes,
+              uint32_t* counters, size_t counter_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * mv2_video_to_ndhwc — API-edge layout change + zero padding.

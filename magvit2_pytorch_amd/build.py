@@ -17,8 +17,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmv2_hip.so')
-SOURCES = ['conv.hip', 'conv_halo.hip', 'conv_halo_rs.hip', 'misc.hip', 'attn.hip', 'quant.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(HERE, '..', 'include', 'mv2.h')]
+# product library: no environment switches, no experimental kernels
+SOURCES = ['conv.hip', 'conv3.hip', 'misc.hip', 'attn.hip', 'quant.hip']
+# experiments library (tools/ only, -DMV2_EXPERIMENTS): + the round-1 halo kernels and their A/B switches
+LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
+SOURCES_EXP = SOURCES + ['conv_halo.hip', 'conv_halo_rs.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv_fused_pw.h'),
+           os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 
@@ -36,19 +41,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, experiments=False):
+    """experiments=True builds libmv2_hip_exp.so (the A/B library of tools/) instead of the product library."""
+    sources, lib, objdir = (SOURCES_EXP, LIB_EXP, OBJ + '_exp') if experiments else (SOURCES, LIB, OBJ)
+    flags = FLAGS + (['-DMV2_EXPERIMENTS'] if experiments else [])
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
-    for s in SOURCES:
+    for s in sources:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace('.hip', '.o'))
+        obj = os.path.join(objdir, s.replace('.hip', '.o'))
         if force or _stale(obj, [src] + HEADERS):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, '-c', src, '-o', obj]
+        cmd = [hipcc, *flags, '-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
@@ -59,16 +67,16 @@ def build(force=False, verbose=True):
             print(f'[mv2 build] compiling {len(jobs)} file(s) for gfx950 ...', flush=True)
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in sources]
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
         if verbose:
-            print(f'[mv2 build] linked {LIB}', flush=True)
-    return LIB
+            print(f'[mv2 build] linked {lib}', flush=True)
+    return lib
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, experiments='--experiments' in sys.argv)

@@ -291,7 +291,11 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
     if (dim_head != 32 || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
     AttnParams p{qkv, mem_kv, out, nseq, n, heads, n_mem, causal, seq_inner, seq_outer_stride, tok_stride};
     hipStream_t st = (hipStream_t)stream;
+#ifdef MV2_EXPERIMENTS
     static const bool no_mfma = getenv("MV2_ATTN_VALU") != nullptr;
+#else
+    constexpr bool no_mfma = false;
+#endif
     if (dtype == MV2_BF16 && !causal && n >= 64 && !no_mfma) {
         if (nseq > 65535) return MV2_EINVAL;
         dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)nseq);

@@ -290,8 +290,12 @@ inline TileCfg pick_tile(const mv2_conv_desc& d) {
     // rows) are chains of latencies, not MFMA work.  They use 64x64 tiles (64x128 for GEGLU, which needs value and
     // gate in one wave): 4x the blocks, a quarter of the per-block epilogue, several blocks per CU to overlap the
     // chains.  Measured at C = 512: 1x1x1 conv 19 -> 9-12 us, to_out 13.5 -> 6.8 us; C = 256: 20.5 -> 16 us.
-    // MV2_SMALL_TILE=0 disables, =1 restricts the rule to launches with fewer than 1 block per CU.
+    // (experiments build: MV2_SMALL_TILE=0 disables, =1 restricts the rule to launches with fewer than 1 block per CU)
+#ifdef MV2_EXPERIMENTS
     static const int small_policy = getenv("MV2_SMALL_TILE") ? atoi(getenv("MV2_SMALL_TILE")) : 2;
+#else
+    constexpr int small_policy = 2;
+#endif
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     const int64_t blocks128 = ((d.co + 127) / 128) * ((M + 127) / 128);
     const bool small = small_policy > 0 && d.co >= 64 && blocks128 < (int64_t)(small_policy >= 2 ? 2 : 1) * device_cus();
@@ -319,6 +323,10 @@ struct Launch {
 
 // stride-1 kt x 3 x 3 "same"/causal convolution over whole 128-byte channel chunks -> halo kernel
 inline bool halo_eligible(const mv2_conv_desc& d) {
+#ifndef MV2_EXPERIMENTS
+    (void)d;
+    return false;      // product build: these convolutions are mv2_conv3's (conv3.hip); mv2_conv keeps the generic kernel
+#else
     static const bool off = getenv("MV2_NO_HALO") != nullptr;
     if (off) return false;
     const int es = d.dtype == MV2_BF16 ? 2 : 4;
@@ -326,15 +334,14 @@ inline bool halo_eligible(const mv2_conv_desc& d) {
            d.pt == d.kt - 1 && d.kt <= 3 && d.check_bounds && d.seg_bytes == 128 && (d.Ci * es) % 128 == 0 &&
            d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) &&
            d.act != MV2_ACT_GEGLU && d.co >= 64;
+#endif
 }
 
-inline int device_cus() {
-    static int g_cus = 0;
-    if (g_cus > 0) return g_cus;
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    return g_cus;
+inline int device_cus() {      // of the CURRENT device; not cached: a process may drive several devices
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
 }
 
 inline int validate(const mv2_conv_desc& d) {
@@ -354,6 +361,7 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     Launch L;
     L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
+#ifdef MV2_EXPERIMENTS
     if (halo_eligible(d)) {
         L.halo = true;
         const int es = d.dtype == MV2_BF16 ? 2 : 4;
@@ -410,6 +418,7 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
         L.ws_cols = L.n_co_tiles * L.t.bco;
         return L;
     }
+#endif
     L.t = pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
@@ -438,12 +447,10 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
     constexpr size_t lds_main = 2 * (size_t)(BCO + BPOS) * 128;
     constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, BPOS>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (lds > 64 * 1024) {   // per-device attribute: set on every call rather than cached in a process-wide flag
         hipError_t e = hipFuncSetAttribute((const void*)conv_kernel<E, BCO, BPOS, WCO, WPOS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     dim3 grid((unsigned)(L.n_co_tiles * L.n_pos_tiles), (unsigned)L.splitk);
     hipLaunchKernelGGL((conv_kernel<E, BCO, BPOS, WCO, WPOS>), grid, dim3(256), lds, st, p);
@@ -454,8 +461,11 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
+#ifdef MV2_EXPERIMENTS
     if (L.halo) rc = mv2_launch_halo(p, L.t.bco, L.th, L.tw, st);
-    else if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1>(p, L, st);
+    else
+#endif
+    if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1>(p, L, st);
     else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1>(p, L, st);
     else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
     else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2>(p, L, st);
@@ -499,16 +509,20 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.out = out; p.ws = (float*)workspace;
     p.wp2 = nullptr; p.bias2 = nullptr; p.act2 = MV2_ACT_NONE;
     p.se_wk = nullptr; p.se_bk = 0.f; p.se_part = nullptr;
+    p.counters = nullptr; p.gtot = 0;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = L.M; p.lg_seg_chunks = ilog2(d->seg_bytes / 16);
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
     p.steps_per_split = L.steps_per_split; p.splitk = L.splitk;
     p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
     p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
+    p.ablate = 0;
+#ifdef MV2_EXPERIMENTS
     {
         static const int ab = getenv("MV2_ABLATE") ? atoi(getenv("MV2_ABLATE")) : 0;   // timing experiments only: results are wrong
         p.ablate = ab;
     }
+#endif
     if (L.splitk > 1) {
         const size_t need = (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
         if (!workspace || workspace_bytes < need) return MV2_EWORKSPACE;
@@ -517,6 +531,8 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     return d->dtype == MV2_BF16 ? launch_dtype<BF16>(p, L, st) : launch_dtype<F32>(p, L, st);
 }
 
+#ifdef MV2_EXPERIMENTS
+// round-1 fused kernel, kept in the experiments build as the A/B baseline of mv2_conv3 (tools/k3_bench.cpp)
 // fused 3x3 causal conv + activation + 1x1x1 conv + activation (ResidualUnit front half), bf16, C <= 128
 extern "C" int mv2_conv_pw_eligible(const mv2_conv_desc* d) {
     if (!d || validate(*d) != MV2_OK) return 0;
@@ -564,6 +580,8 @@ extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_byt
     p.ablate = 0;
     return mv2_launch_halo(p, L.t.bco, L.th, L.tw, (hipStream_t)stream);
 }
+
+#endif
 
 extern "C" int mv2_abi_version(void) { return MV2_ABI_VERSION; }
 extern "C" int mv2_device_cus(void) {

@@ -36,13 +36,20 @@ struct ConvParams {
     const float* se_wk;
     float se_bk;
     float* se_part;
+    // conv3.hip: stream-K ticket words (one per output tile, zero between launches) and the length of the group list
+    uint32_t* counters;
+    uint32_t gtot;
 };
 
+#ifdef MV2_EXPERIMENTS
+// Round-1 kernels, compiled only into libmv2_hip_exp.so (A/B baselines for tools/; the product library has neither
+// these kernels nor any environment switch):
 // conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice
 int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st);
-// conv_halo_rs.hip: role-specialised 8-wave variant (MV2_HALO_RS=1 only; not yet validated on a GPU)
+// conv_halo_rs.hip: role-specialised 8-wave variant (MV2_HALO_RS=1 only)
 bool mv2_halo_rs_eligible(const ConvParams& p, int bco, int th, int tw);
 int mv2_launch_halo_rs(const ConvParams& p, hipStream_t st);
+#endif
 
 // ------------------------------------------------------------------------------- epilogue
 template <typename E>

@@ -71,6 +71,7 @@ class PackedConv:
     kw: int
     k_real: int = 0                   # un-padded reduction length (algorithmic FLOP accounting)
     co_real: int = 0                  # reference output channels
+    frag_major: bool = False          # wp is in mv2_conv3's MFMA-fragment order (include/mv2.h), not mv2_conv's
 
     def to(self, device):
         self.wp = self.wp.to(device)
@@ -147,9 +148,29 @@ def conv_taps(w: torch.Tensor) -> List[Tap]:
     return [Tap(it, ih, iw, 0, w[:, :, it, ih, iw].float()) for it in range(kt) for ih in range(kh) for iw in range(kw)]
 
 
-def pack_conv3d(w, bias, dtype):
+def to_frag_major(wp: torch.Tensor) -> torch.Tensor:
+    """[nsteps][co_pad][128 B] -> mv2_conv3's weight image (include/mv2.h): every group of 32 output rows becomes
+    [k-slice 4][half 2][row 32][16 B], where 16-byte chunk (2*k-slice + half) of row r of the plain layout is meant —
+    one contiguous 1 KB block per (row group, k-slice) = one wave's MFMA A-fragments, loaded with one instruction."""
+    ns, cp, kel = wp.shape
+    e16 = kel // 8                                        # elements per 16-byte chunk
+    return wp.reshape(ns, cp // 32, 32, 4, 2, e16).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(ns, cp, kel)
+
+
+def conv3_packable(w, dtype) -> bool:
+    """weights of a convolution mv2_conv3 can run (kt <= 3, 3 x 3 in space, whole 128-byte channel chunks, C_out >= 64)."""
     co, ci, kt, kh, kw = w.shape
-    return pack_taps(conv_taps(w), co, dtype, bias, kt, kh, kw)
+    return kt <= 3 and kh == 3 and kw == 3 and (ci * esize(dtype)) % 128 == 0 and co >= 64 and co % 4 == 0
+
+
+def pack_conv3d(w, bias, dtype, frag_major=False):
+    co, ci, kt, kh, kw = w.shape
+    pc = pack_taps(conv_taps(w), co, dtype, bias, kt, kh, kw)
+    if frag_major:
+        assert pc.seg_bytes == 128 and pc.nsteps == kt * kh * kw * (ci * esize(dtype) // 128)
+        pc.wp = to_frag_major(pc.wp)
+        pc.frag_major = True
+    return pc
 
 
 def pack_pointwise(w2d, bias, dtype, in_scale: Optional[torch.Tensor] = None, k_pad: Optional[int] = None):

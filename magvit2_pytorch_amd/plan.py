@@ -44,7 +44,8 @@ class PackedModel:
         put('conv_out', P.pack_conv3d(f('conv_out.conv.weight'), f('conv_out.conv.bias'), dtype))
 
         def residual_unit(pre):
-            put(pre + '.k3', P.pack_conv3d(f(pre + '.fn.0.conv.weight'), f(pre + '.fn.0.conv.bias'), dtype))
+            w3 = f(pre + '.fn.0.conv.weight')
+            put(pre + '.k3', P.pack_conv3d(w3, f(pre + '.fn.0.conv.bias'), dtype, frag_major=P.conv3_packable(w3, dtype)))
             put(pre + '.k1', P.pack_pointwise(f(pre + '.fn.2.weight').flatten(1), f(pre + '.fn.2.bias'), dtype))
             c = sd[pre + '.fn.2.weight'].shape[0]
             self.f32[pre + '.se.wk'] = dev(f(pre + '.fn.4.to_k.weight').reshape(c).contiguous())
@@ -183,6 +184,7 @@ class Plan:
         self.want_prequant = want_prequant
         self.step_names: List[str] = []
         self.step_flops: Dict[int, float] = {}      # id(step) -> algorithmic FLOPs (conv launches)
+        self._ticket_buf = None
         ch = self.cfg['channels']
         ops = self.ops
         # static I/O
@@ -251,31 +253,48 @@ class Plan:
             self.arena.put(ws)
         return out
 
-    def _conv_pw(self, steps, pre, x: Act, k, se_part_for=None):
-        """Fused conv3 + ELU + conv1 + ELU launch (mv2_conv_pw) if the ABI offers it for this shape, else None.
-        Returns (output, pooling partials or None); partials = (buffer, records per frame) when the kernel was also
-        asked for the SqueezeExcite pooling records of unit `se_part_for`."""
-        pm = self.pm
+    def _conv3(self, steps, pre, x: Act, k, fuse_k1: bool, se_part_for=None):
+        """The ResidualUnit's k x 3 x 3 causal conv + ELU through mv2_conv3; with fuse_k1 also the 1x1x1 conv + ELU (and, with
+        se_part_for, the SqueezeExcite pooling partials of that unit) in the same launch.
+        Returns (output, (partials, records per frame) or None)."""
+        pm, ops = self.pm, self.ops
         pc, pc2 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1,
                  sw=1, pt=k - 1, ph=k // 2, pw=k // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes,
                  check_bounds=1, act=P.ACT_ELU, store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
-        if pc2.co != pc.co or pc2.kt != 1 or not getattr(self.ops, 'conv_pw_eligible', lambda _d: False)(d):
-            return None
+        assert ops.conv3_eligible(d), 'fragment-major weights but the descriptor is not mv2_conv3-eligible'
         out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
-        segs = pc.segs_tensor(x.H, x.W, x.C, self.ops.device)
-        se, pw_part = {}, None
-        if se_part_for is not None and hasattr(self.ops, 'conv_pw_tiles') and not os.environ.get('MV2_NO_FUSE_POOL'):
-            # the fused kernel also emits the SqueezeExcite pooling partials of its tiles (one record per tile)
-            n, _, _ = self.ops.conv_pw_tiles(d)
-            part = self.arena.get(x.B * x.T * n * (pc.co + 2), torch.float32)
-            se = dict(se_wk=pm.f32[se_part_for + '.se.wk'], se_bk=float(pm.f32[se_part_for + '.se.bk']), se_part=part)
-            pw_part = (part, n)
-        steps.append(self.ops.conv_pw(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, segs, pc.bias, pc2.wp, pc2.bias, P.ACT_ELU, out.t, **se))
-        steps[-1].label = pre + '.k3+k1'
-        self.step_flops[id(steps[-1])] = 2.0 * x.rows * pc.co_real * pc.k_real + 2.0 * x.rows * pc2.co_real * pc2.k_real
-        self.step_names.append(pre + '.k3+k1')
+        ws_bytes, cnt_bytes = ops.conv3_sizes(d)
+        ws = self.arena.get((ws_bytes + 3) // 4, torch.float32) if ws_bytes > 0 else None
+        kw, pw_part = {}, None
+        if fuse_k1:
+            kw = dict(wp2=pc2.wp, bias2=pc2.bias, act2=P.ACT_ELU)
+            if se_part_for is not None:
+                n, _, _ = ops.conv3_tiles(d)
+                part = self.arena.get(x.B * x.T * n * (pc.co + 2), torch.float32)
+                kw.update(se_wk=pm.f32[se_part_for + '.se.wk'], se_bk=float(pm.f32[se_part_for + '.se.bk']), se_part=part)
+                pw_part = (part, n)
+        steps.append(ops.conv3(d, x.t, x.t.numel() * x.t.element_size(), pc.wp, pc.bias, out.t, ws, self._tickets(cnt_bytes), **kw))
+        label = pre + ('.k3+k1' if fuse_k1 else '.k3')
+        steps[-1].label = label
+        fl = 2.0 * x.rows * pc.co_real * pc.k_real
+        self.step_flops[id(steps[-1])] = fl + (2.0 * x.rows * pc2.co_real * pc2.k_real if fuse_k1 else 0.0)
+        self.step_names.append(label)
+        if ws is not None:
+            self.arena.put(ws)
         return out, pw_part
+
+    def _tickets(self, nbytes):
+        """One zero-initialised ticket buffer shared by every mv2_conv3 launch of the plan (each launch leaves it zero)."""
+        n = (int(nbytes) + 3) // 4
+        if n == 0:
+            return None
+        if self._ticket_buf is None:
+            # upper bound of the tile count of any level: 8 x 16 tiles of the input resolution, <= 4 channel tiles
+            cap = self.B * (self.T + self.time_padding) * (-(-self.H // 8)) * (-(-self.W // 16)) * 4
+            self._ticket_buf = self.ops.zeros((max(cap, n),), torch.int32)
+        assert self._ticket_buf.numel() >= n, 'ticket buffer too small for this level'
+        return self._ticket_buf
 
     def _rms(self, steps, x: Act, shift: bool):
         rs = self.arena.get(x.rows, torch.float32)
@@ -289,12 +308,20 @@ class Plan:
         frames, Pn, C = x.B * x.T, x.H * x.W, x.C
         hidden = se_hidden(C)
         two = _se_two_launch(Pn, C, hidden, self.dtype)
-        # fused conv3 + ELU + conv1 + ELU (+ SE pooling partials) where the ABI offers it (bf16, C <= 128)
-        fused = self._conv_pw(steps, pre, x, k, se_part_for=None if two else pre)
-        y2, pw_part = fused if fused is not None else (None, None)
-        if y2 is None:
-            y1 = self._conv(steps, pre + '.k3', pm.convs[pre + '.k3'], x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
-            y2 = self._conv(steps, pre + '.k1', pm.convs[pre + '.k1'], y1, act=P.ACT_ELU, check_bounds=False)
+        pc3, pc1 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
+        pw_part = None
+        if pc3.frag_major:
+            # mv2_conv3; bf16 at C <= 128 (a block owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
+            fuse = self.dtype == torch.bfloat16 and pc3.co in (64, 128) and pc1.co == pc3.co and pc1.kt == 1
+            y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and not os.environ.get('MV2_NO_FUSE_POOL') else None))
+            if fuse:
+                y2 = y1
+            else:
+                y2 = self._conv(steps, pre + '.k1', pc1, y1, act=P.ACT_ELU, check_bounds=False)
+                self.arena.put(y1.t)
+        else:
+            y1 = self._conv(steps, pre + '.k3', pc3, x, pt=k - 1, ph=k // 2, pw=k // 2, act=P.ACT_ELU)
+            y2 = self._conv(steps, pre + '.k1', pc1, y1, act=P.ACT_ELU, check_bounds=False)
             self.arena.put(y1.t)
         if two:
             # frames small enough for one workgroup to pool: two wide launches instead of three latency chains

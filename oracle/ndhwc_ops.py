@@ -139,30 +139,68 @@ class CpuOps:
         step.what = 'conv'
         return step
 
-    def conv_pw_eligible(self, d):
-        # mirrors mv2_conv_pw_eligible() so the CPU plan has the same launch sequence as the HIP plan
-        import os
-        if os.environ.get('MV2_NO_FUSE_PW') or os.environ.get('MV2_NO_HALO'):
-            return False
+    # ------------------------------------------------------------------ mv2_conv3 (include/mv2.h)
+    def conv3_eligible(self, d):
+        # mirrors mv2_conv3_eligible() so the CPU plan has the same launch sequence as the HIP plan
         es = 2 if d['dtype'] == 0 else 4
-        return (d['dtype'] == 0 and d['kh'] == 3 and d['kw'] == 3 and d['st'] == d['sh'] == d['sw'] == 1 and d['ph'] == d['pw'] == 1
-                and d['pt'] == d['kt'] - 1 and d['kt'] <= 3 and d['check_bounds'] and d['seg_bytes'] == 128 and (d['Ci'] * es) % 128 == 0
+        return (d['dtype'] in (0, 1) and d['kh'] == 3 and d['kw'] == 3 and d['st'] == d['sh'] == d['sw'] == 1 and d['ph'] == d['pw'] == 1
+                and 1 <= d['kt'] <= 3 and d['pt'] == d['kt'] - 1 and d['check_bounds'] and (d['Ci'] * es) % 128 == 0
                 and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['nsteps'] == d['kt'] * 9 * ((d['Ci'] * es) // 128)
-                and d['co'] in (64, 128) and d['store'] == STORE_ROWS and d['out_c'] == d['co'] and d['act'] != ACT_GEGLU)
+                and d['act'] != ACT_GEGLU and d['co'] >= 64 and d['co_pad'] % 128 == 0 and d['store'] != STORE_NCTHW_F32
+                and d['co'] % 4 == 0 and d['out_c'] % 4 == 0)
 
-    def conv_pw_tiles(self, d):
-        # tile menu of conv_halo.hip for the fused kernel: 16x16 positions at C <= 64, 8x16 above
+    def conv3_sizes(self, d):
+        return 0, 0
+
+    def conv3_tiles(self, d):
+        # tile menu of conv3.hip: 16x16 positions at C_out <= 64, 8x16 above
         th, tw = (16, 16) if d['co'] <= 64 else (8, 16)
         return (-(-d['Ho'] // th)) * (-(-d['Wo'] // tw)), th, tw
 
-    def conv_pw(self, d, x, in_bytes, wp, segs, bias, wp2, bias2, act2, out, se_wk=None, se_bk=0.0, se_part=None):
-        """fused 3x3 conv + act, then 1x1x1 conv + act2 (include/mv2.h mv2_conv_pw): the intermediate is rounded
-        to the storage dtype exactly like the kernel's LDS tile."""
+    @staticmethod
+    def _plain_from_frag_major(wp3):
+        """inverse of the weight image mv2.h describes for mv2_conv3: [step][co_pad/32][k-slice 4][half 2][row 32][16 B]
+        holds 16-byte chunk (2*k-slice + half) of row r of the plain [step][co_pad][128 B] layout."""
+        ns, cp, kel = wp3.shape
+        e16 = kel // 8
+        src = wp3.reshape(ns, cp // 32, 4, 2, 32, e16)
+        plain = torch.empty(ns, cp // 32, 32, 8, e16, dtype=wp3.dtype)
+        for ks in range(4):
+            for half in range(2):
+                plain[:, :, :, 2 * ks + half, :] = src[:, :, ks, half, :, :]
+        return plain.reshape(ns, cp, kel)
+
+    def conv3(self, d, x, in_bytes, wp3, bias, out, ws, counters, rowscale=None, residual=None, wp2=None, bias2=None, act2=0,
+              se_wk=None, se_bk=0.0, se_part=None):
+        """stride-1 kt x 3 x 3 causal conv (+ bias, act), optionally followed by the 1x1x1 conv (+ bias2, act2) and the per-tile
+        SqueezeExcite pooling partials (include/mv2.h mv2_conv3): the intermediate is rounded to the storage dtype exactly
+        like the kernel's LDS tile."""
+        es = x.element_size()
+        kel = 128 // es
+        nchunk = d['Ci'] * es // 128
+        Hi, Wi, Ci = d['Hi'], d['Wi'], d['Ci']
+        rows = []
+        for it in range(d['kt']):
+            for ih in range(3):
+                for iw in range(3):
+                    for ch in range(nchunk):
+                        rows.append((((it * Hi + ih) * Wi + iw) * Ci + ch * kel, (1 << it) | (1 << (8 + ih)) | (1 << (16 + iw))))
+        segs = torch.tensor(rows, dtype=torch.int32)
+        wp = self._plain_from_frag_major(wp3)
         M = d['B'] * d['To'] * d['Ho'] * d['Wo']
         co = d['co']
+        dd = dict(d, seg_bytes=128)
+        if wp2 is None:
+            first = self.conv(dd, x, in_bytes, wp, segs, bias, rowscale, residual, out, None)
+
+            def step(stream):
+                first(stream)
+            step.outs = [out]
+            step.what = 'conv3'
+            return step
+        assert rowscale is None and residual is None
         mid = torch.full((M * co,), float('nan'), dtype=x.dtype)
-        first = self.conv(d, x, in_bytes, wp, segs, bias, None, None, mid, None)
-        es = x.element_size()
+        first = self.conv(dd, x, in_bytes, wp, segs, bias, None, None, mid, None)
         d2 = dict(d, Ti=d['To'], Hi=d['Ho'], Wi=d['Wo'], Ci=co, kt=1, kh=1, kw=1, pt=0, ph=0, pw=0, nsteps=co * es // 128,
                   seg_bytes=128, check_bounds=0, act=act2)
         segs2 = torch.tensor([[j * (128 // es), (1 << 0) | (1 << 8) | (1 << 16)] for j in range(co * es // 128)], dtype=torch.int32)
@@ -170,7 +208,7 @@ class CpuOps:
 
         def pool(stream):
             # per-tile SqueezeExcite pooling partials from the stored (rounded) output, mv2_se_pool record format
-            n, th, tw = self.conv_pw_tiles(d)
+            n, th, tw = self.conv3_tiles(d)
             B, T, H, W = d['B'], d['To'], d['Ho'], d['Wo']
             y = out[: M * co].reshape(B * T, H, W, co).to(self.acc)
             logits = y @ se_wk.to(self.acc) + se_bk
@@ -192,7 +230,7 @@ class CpuOps:
             if se_part is not None:
                 pool(stream)
         step.outs = [o for o in [out, se_part] if o is not None]
-        step.what = 'conv_pw'
+        step.what = 'conv3'
         return step
 
     # ------------------------------------------------------------------ layout edge

@@ -110,29 +110,13 @@ def test_lockstep_full_channel_widths(dtype):
 
 def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     """Forces the pool / gate / apply form of SqueezeExcite at every level, so the pooling partials written by the
-    fused conv kernel (mv2_conv_pw se_part; several 16x16 and 8x16 tiles per frame at 32x32) and mv2_se_pool /
+    fused conv kernel (mv2_conv3 se_part; several 16x16 and 8x16 tiles per frame at 32x32) and mv2_se_pool /
     mv2_se_gate at C = 256 / 512 are all compared launch by launch."""
     monkeypatch.setenv('MV2_SE_THREE', '1')
     kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
     cfg = make_cfg(**kw)
     sd = init_state_dict(cfg, seed=9, randomize_se=True)
     v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(10))
-    run_lockstep(cfg, sd, v, torch.bfloat16)
-
-
-@pytest.mark.skipif(not os.environ.get('MV2_TEST_EXPERIMENTAL'),
-                    reason='kernel variants that are off by default and not validated yet: set MV2_TEST_EXPERIMENTAL=1')
-@pytest.mark.parametrize('switch', ['MV2_HALO_RS', 'MV2_HALO_EW'])
-def test_lockstep_experimental_halo_variants(switch, monkeypatch):
-    """Launch-by-launch parity of the opt-in halo-conv variants (role-specialised kernel, early weight write) on the
-    real channel widths with several tiles per frame.  Both switches are read per launch, so one process can test
-    them; nothing here runs unless MV2_TEST_EXPERIMENTAL is set."""
-    monkeypatch.setenv(switch, '1')
-    monkeypatch.setenv('MV2_NO_FUSE_PW', '1')          # the role-specialised kernel covers the non-fused launches
-    kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
-    cfg = make_cfg(**kw)
-    sd = init_state_dict(cfg, seed=11, randomize_se=True)
-    v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(12))
     run_lockstep(cfg, sd, v, torch.bfloat16)
 
 

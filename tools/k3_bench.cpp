@@ -1,0 +1,272 @@
+// tools/k3_bench.cpp — standalone A/B + correctness harness for mv2_conv3 (conv3.hip) against
+//   (1) a plain CPU reference (small shapes, fp64 accumulate) and
+//   (2) the round-1 halo kernel (mv2_conv / mv2_conv_pw of libmv2_hip_exp.so) on the real level shapes,
+// plus run-to-run determinism, ticket-word hygiene and per-launch timing (HIP events, back-to-back launches).
+// Build (no GPU needed):  hipcc -O2 -std=c++17 tools/k3_bench.cpp -o tools/k3_bench -ldl
+// Run on the GPU box:     tools/k3_bench [path to libmv2_hip_exp.so]
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/mv2.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef int (*conv_fn)(const mv2_conv_desc*, const void*, size_t, const void*, const mv2_seg*, const float*, const float*, const void*, void*, void*, size_t, void*);
+typedef size_t (*ws_fn)(const mv2_conv_desc*);
+typedef int (*conv3_fn)(const mv2_conv_desc*, const void*, size_t, const void*, const float*, const float*, const void*, const void*, const float*, int,
+                        const float*, float, float*, void*, void*, size_t, uint32_t*, size_t, void*);
+typedef int (*convpw_fn)(const mv2_conv_desc*, const void*, size_t, const void*, const mv2_seg*, const float*, const void*, const float*, int, const float*,
+                         float, float*, void*, void*);
+typedef int (*tiles_fn)(const mv2_conv_desc*, int*, int*);
+
+static conv_fn p_conv; static ws_fn p_conv_ws, p_c3_ws, p_c3_cnt; static conv3_fn p_conv3; static convpw_fn p_convpw; static tiles_fn p_c3_tiles;
+
+static uint32_t rng_state = 12345u;
+static inline float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
+static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Shape { int B, T, H, W, C, kt; };
+
+struct Case {
+    Shape s; int es;          // element size 2 / 4
+    mv2_conv_desc d;
+    std::vector<uint8_t> in, wp, wp3, wp2;        // host images
+    std::vector<float> bias, bias2, se_wk;
+    std::vector<mv2_seg> segs;
+    void *d_in, *d_wp, *d_wp3, *d_wp2, *d_bias, *d_bias2, *d_sewk, *d_segs;
+    size_t in_bytes, M;
+};
+
+static void put_elem(std::vector<uint8_t>& v, size_t i, float f, int es) {
+    if (es == 2) { uint16_t h = f2bf(f); memcpy(&v[i * 2], &h, 2); } else memcpy(&v[i * 4], &f, 4);
+}
+static float get_elem(const std::vector<uint8_t>& v, size_t i, int es) {
+    if (es == 2) { uint16_t h; memcpy(&h, &v[i * 2], 2); return bf2f(h); }
+    float f; memcpy(&f, &v[i * 4], 4); return f;
+}
+
+static void* to_dev(const void* h, size_t n) { void* d; CK(hipMalloc(&d, n ? n : 16)); if (n) CK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return d; }
+
+static Case make_case(Shape s, int es) {
+    Case c; c.s = s; c.es = es;
+    const int C = s.C, kel = 128 / es, nchunk = C * es / 128, co_pad = (C + 127) / 128 * 128, nsteps = s.kt * 9 * nchunk;
+    mv2_conv_desc& d = c.d; memset(&d, 0, sizeof(d));
+    d.dtype = es == 2 ? MV2_BF16 : MV2_F32; d.B = s.B; d.Ti = d.To = s.T; d.Hi = d.Ho = s.H; d.Wi = d.Wo = s.W; d.Ci = C; d.co = C; d.co_pad = co_pad;
+    d.st = d.sh = d.sw = 1; d.pt = s.kt - 1; d.ph = d.pw = 1; d.kt = s.kt; d.kh = d.kw = 3; d.nsteps = nsteps; d.seg_bytes = 128; d.check_bounds = 1;
+    d.act = MV2_ACT_ELU; d.store = MV2_STORE_ROWS; d.rt = d.rh = d.rw = 1; d.out_c = C; d.splitk = 0;
+    c.M = (size_t)s.B * s.T * s.H * s.W;
+    c.in_bytes = c.M * C * es;
+    c.in.resize(c.in_bytes);
+    for (size_t i = 0; i < c.M * C; ++i) put_elem(c.in, i, frand(), es);
+    // plain packed weights [step][co_pad][kel], scaled so outputs are O(1)
+    const float wscale = 1.0f / sqrtf((float)(27 * C) / 3.0f);
+    c.wp.assign((size_t)nsteps * co_pad * 128, 0);
+    for (int st = 0; st < nsteps; ++st)
+        for (int n = 0; n < C; ++n)
+            for (int k = 0; k < kel; ++k) put_elem(c.wp, ((size_t)st * co_pad + n) * kel + k, frand() * wscale * 1.7f, es);
+    // fragment-major: [step][co_pad/32][ks 4][half 2][row 32][16 B]  <-  16-byte chunk (2 ks + half) of row r
+    c.wp3.assign(c.wp.size(), 0);
+    for (int st = 0; st < nsteps; ++st)
+        for (int g = 0; g < co_pad / 32; ++g)
+            for (int ks = 0; ks < 4; ++ks)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int r = 0; r < 32; ++r) {
+                        const size_t src = ((size_t)st * co_pad + g * 32 + r) * 128 + (size_t)(2 * ks + hf) * 16;
+                        const size_t dst = ((((size_t)st * (co_pad / 32) + g) * 4 + ks) * 2 + hf) * 512 + (size_t)r * 16;
+                        memcpy(&c.wp3[dst], &c.wp[src], 16);
+                    }
+    c.bias.resize(co_pad); for (auto& b : c.bias) b = frand() * 0.1f;
+    // pointwise second stage (bf16 only): [C/64][co_pad][64]
+    const int ns2 = C * es / 128;
+    c.wp2.assign((size_t)ns2 * co_pad * 128, 0);
+    const float w2s = 1.0f / sqrtf((float)C / 3.0f);
+    for (int st = 0; st < ns2; ++st)
+        for (int n = 0; n < C; ++n)
+            for (int k = 0; k < kel; ++k) put_elem(c.wp2, ((size_t)st * co_pad + n) * kel + k, frand() * w2s, es);
+    c.bias2.resize(co_pad); for (auto& b : c.bias2) b = frand() * 0.1f;
+    c.se_wk.resize(C); for (auto& b : c.se_wk) b = frand() * 0.2f;
+    // K program of the generic / halo kernel: step = tap * nchunk + chunk
+    c.segs.resize(nsteps);
+    for (int it = 0; it < s.kt; ++it) for (int ih = 0; ih < 3; ++ih) for (int iw = 0; iw < 3; ++iw) for (int ch = 0; ch < nchunk; ++ch) {
+        mv2_seg sg; sg.elem_offset = ((it * s.H + ih) * s.W + iw) * C + ch * kel; sg.sel = (1u << it) | (1u << (8 + ih)) | (1u << (16 + iw));
+        c.segs[((it * 3 + ih) * 3 + iw) * nchunk + ch] = sg;
+    }
+    c.d_in = to_dev(c.in.data(), c.in.size()); c.d_wp = to_dev(c.wp.data(), c.wp.size()); c.d_wp3 = to_dev(c.wp3.data(), c.wp3.size());
+    c.d_wp2 = to_dev(c.wp2.data(), c.wp2.size()); c.d_bias = to_dev(c.bias.data(), c.bias.size() * 4); c.d_bias2 = to_dev(c.bias2.data(), c.bias2.size() * 4);
+    c.d_sewk = to_dev(c.se_wk.data(), c.se_wk.size() * 4); c.d_segs = to_dev(c.segs.data(), c.segs.size() * sizeof(mv2_seg));
+    return c;
+}
+static void free_case(Case& c) { for (void* p : {c.d_in, c.d_wp, c.d_wp3, c.d_wp2, c.d_bias, c.d_bias2, c.d_sewk, c.d_segs}) hipFree(p); }
+
+static float elu(float v) { return v > 0 ? v : expm1f(v); }
+
+// plain CPU reference of conv + bias + ELU (fp64 accumulate), output rounded to the storage dtype
+static std::vector<float> cpu_ref(const Case& c) {
+    const Shape& s = c.s; const int C = s.C, es = c.es, kel = 128 / es, nchunk = C * es / 128, co_pad = c.d.co_pad;
+    std::vector<float> inf(c.M * C); for (size_t i = 0; i < inf.size(); ++i) inf[i] = get_elem(c.in, i, es);
+    std::vector<float> wf(c.wp.size() / es); for (size_t i = 0; i < wf.size(); ++i) wf[i] = get_elem(c.wp, i, es);
+    std::vector<float> out(c.M * C);
+    for (int b = 0; b < s.B; ++b) for (int t = 0; t < s.T; ++t) for (int h = 0; h < s.H; ++h) for (int w = 0; w < s.W; ++w) {
+        const size_t m = (((size_t)b * s.T + t) * s.H + h) * s.W + w;
+        std::vector<double> acc(C, 0.0);
+        for (int it = 0; it < s.kt; ++it) { const int ti = t + it - (s.kt - 1); if (ti < 0) continue;
+            for (int ih = 0; ih < 3; ++ih) { const int hi = h + ih - 1; if (hi < 0 || hi >= s.H) continue;
+                for (int iw = 0; iw < 3; ++iw) { const int wi = w + iw - 1; if (wi < 0 || wi >= s.W) continue;
+                    const float* xr = &inf[((((size_t)b * s.T + ti) * s.H + hi) * s.W + wi) * C];
+                    for (int ch = 0; ch < nchunk; ++ch) {
+                        const size_t st = ((it * 3 + ih) * 3 + iw) * nchunk + ch;
+                        for (int n = 0; n < C; ++n) { const float* wr = &wf[(st * co_pad + n) * kel]; double a = 0; for (int k = 0; k < kel; ++k) a += (double)wr[k] * xr[ch * kel + k]; acc[n] += a; }
+                    } } } }
+        for (int n = 0; n < C; ++n) out[m * C + n] = elu((float)acc[n] + c.bias[n]);
+    }
+    return out;
+}
+
+struct Diff { double max_abs, mean_abs; size_t nbad; };
+static Diff compare(const std::vector<uint8_t>& a, const std::vector<float>& ref, int es, double atol, double rtol) {
+    Diff d{0, 0, 0};
+    for (size_t i = 0; i < ref.size(); ++i) { const double x = get_elem(a, i, es), r = ref[i], e = fabs(x - r); d.max_abs = e > d.max_abs ? e : d.max_abs; d.mean_abs += e;
+        if (!(e <= atol + rtol * fabs(r))) ++d.nbad; }
+    d.mean_abs /= ref.size() ? ref.size() : 1; return d;
+}
+static std::vector<float> to_float(const std::vector<uint8_t>& a, size_t n, int es) { std::vector<float> f(n); for (size_t i = 0; i < n; ++i) f[i] = get_elem(a, i, es); return f; }
+
+struct Bufs { void *out, *ws, *ws3, *part; uint32_t* cnt; size_t ws_bytes, ws3_bytes, cnt_bytes, out_bytes, part_bytes; };
+
+static int run_new(const Case& c, Bufs& b, bool fused, bool se, hipStream_t st) {
+    return p_conv3(&c.d, c.d_in, c.in_bytes, c.d_wp3, (const float*)c.d_bias, nullptr, nullptr, fused ? c.d_wp2 : nullptr, fused ? (const float*)c.d_bias2 : nullptr,
+                   MV2_ACT_ELU, se ? (const float*)c.d_sewk : nullptr, 0.05f, se ? (float*)b.part : nullptr, b.out, b.ws3, b.ws3_bytes, b.cnt, b.cnt_bytes, st);
+}
+static int run_old(const Case& c, Bufs& b, bool fused, bool se, hipStream_t st) {
+    if (fused) return p_convpw(&c.d, c.d_in, c.in_bytes, c.d_wp, (const mv2_seg*)c.d_segs, (const float*)c.d_bias, c.d_wp2, (const float*)c.d_bias2, MV2_ACT_ELU,
+                               se ? (const float*)c.d_sewk : nullptr, 0.05f, se ? (float*)b.part : nullptr, b.out, st);
+    return p_conv(&c.d, c.d_in, c.in_bytes, c.d_wp, (const mv2_seg*)c.d_segs, (const float*)c.d_bias, nullptr, nullptr, b.out, b.ws, b.ws_bytes, st);
+}
+
+template <typename F> static float time_us(F f, int reps, hipStream_t st) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms * 1000.f / reps;
+}
+
+static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused, int reps, hipStream_t st) {
+    Case c = make_case(s, es);
+    Bufs b{}; b.out_bytes = c.M * s.C * es; CK(hipMalloc(&b.out, b.out_bytes));
+    b.ws_bytes = p_conv_ws ? p_conv_ws(&c.d) : 0; CK(hipMalloc(&b.ws, b.ws_bytes ? b.ws_bytes : 16));
+    b.ws3_bytes = p_c3_ws(&c.d); CK(hipMalloc(&b.ws3, b.ws3_bytes ? b.ws3_bytes : 16));
+    b.cnt_bytes = p_c3_cnt(&c.d); CK(hipMalloc((void**)&b.cnt, b.cnt_bytes ? b.cnt_bytes : 16)); CK(hipMemset(b.cnt, 0, b.cnt_bytes ? b.cnt_bytes : 16));
+    int th = 0, tw = 0; const int ntile = p_c3_tiles(&c.d, &th, &tw);
+    b.part_bytes = (size_t)s.B * s.T * ntile * (s.C + 2) * 4; CK(hipMalloc(&b.part, b.part_bytes));
+    bool ok = true;
+    const size_t n = c.M * s.C;
+    const double atol = es == 2 ? 2e-2 : 2e-4, rtol = es == 2 ? 2e-2 : 2e-4;
+    printf("== C=%d T=%d H=%d W=%d B=%d kt=%d %s  (tiles %dx%d, slabs %.1f MB, tickets %zu)\n", s.C, s.T, s.H, s.W, s.B, s.kt, es == 2 ? "bf16" : "fp32", th, tw,
+           b.ws3_bytes / 1048576.0, b.cnt_bytes / 4);
+    // --- new kernel, plain
+    CK(hipMemset(b.out, 0xff, b.out_bytes));
+    int rc = run_new(c, b, false, false, st); CK(hipStreamSynchronize(st));
+    if (rc != 0) { printf("   mv2_conv3 rc=%d\n", rc); return false; }
+    std::vector<uint8_t> o_new(b.out_bytes); CK(hipMemcpy(o_new.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost));
+    // determinism + ticket hygiene
+    std::vector<uint32_t> cnt(b.cnt_bytes / 4 + 1);
+    CK(hipMemcpy(cnt.data(), b.cnt, b.cnt_bytes, hipMemcpyDeviceToHost));
+    size_t nz = 0; for (size_t i = 0; i < b.cnt_bytes / 4; ++i) nz += cnt[i] != 0;
+    if (nz) { printf("   FAIL: %zu ticket words non-zero after the launch\n", nz); ok = false; }
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(b.out, 0xff, b.out_bytes));
+        run_new(c, b, false, false, st); CK(hipStreamSynchronize(st));
+        std::vector<uint8_t> o2(b.out_bytes); CK(hipMemcpy(o2.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost));
+        if (memcmp(o2.data(), o_new.data(), b.out_bytes) != 0) { printf("   FAIL: run %d differs bitwise from run 0\n", rep + 1); ok = false; }
+    }
+    if (do_cpu) {
+        std::vector<float> ref = cpu_ref(c);
+        Diff d = compare(o_new, ref, es, atol, rtol);
+        printf("   new vs CPU ref : max|d| %.3e mean|d| %.3e bad %zu / %zu  %s\n", d.max_abs, d.mean_abs, d.nbad, n, d.nbad ? "FAIL" : "ok");
+        ok &= d.nbad == 0;
+    }
+    std::vector<uint8_t> o_old;
+    if (do_old && p_conv) {
+        CK(hipMemset(b.out, 0xff, b.out_bytes));
+        rc = run_old(c, b, false, false, st); CK(hipStreamSynchronize(st));
+        if (rc != 0) printf("   old mv2_conv rc=%d\n", rc);
+        else {
+            o_old.resize(b.out_bytes); CK(hipMemcpy(o_old.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost));
+            Diff d = compare(o_new, to_float(o_old, n, es), es, atol * 0.5, rtol * 0.5);
+            printf("   new vs old halo: max|d| %.3e mean|d| %.3e bad %zu / %zu  %s\n", d.max_abs, d.mean_abs, d.nbad, n, d.nbad ? "FAIL" : "ok");
+            ok &= d.nbad == 0;
+        }
+    }
+    if (do_fused && es == 2 && s.C <= 128) {
+        CK(hipMemset(b.out, 0xff, b.out_bytes)); CK(hipMemset(b.part, 0xff, b.part_bytes));
+        rc = run_new(c, b, true, true, st); CK(hipStreamSynchronize(st));
+        if (rc != 0) { printf("   fused mv2_conv3 rc=%d\n", rc); ok = false; }
+        std::vector<uint8_t> f_new(b.out_bytes), p_new(b.part_bytes);
+        CK(hipMemcpy(f_new.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(p_new.data(), b.part, b.part_bytes, hipMemcpyDeviceToHost));
+        if (p_convpw) {
+            CK(hipMemset(b.out, 0xff, b.out_bytes)); CK(hipMemset(b.part, 0xff, b.part_bytes));
+            rc = run_old(c, b, true, true, st); CK(hipStreamSynchronize(st));
+            if (rc != 0) printf("   old mv2_conv_pw rc=%d\n", rc);
+            else {
+                std::vector<uint8_t> f_old(b.out_bytes), p_old(b.part_bytes);
+                CK(hipMemcpy(f_old.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(p_old.data(), b.part, b.part_bytes, hipMemcpyDeviceToHost));
+                Diff d = compare(f_new, to_float(f_old, n, 2), 2, 2e-2, 2e-2);
+                Diff dp = compare(p_new, to_float(p_old, b.part_bytes / 4, 4), 4, 5e-2, 2e-2);
+                printf("   fused new vs old: out max|d| %.3e bad %zu; SE partials max|d| %.3e bad %zu / %zu  %s\n", d.max_abs, d.nbad, dp.max_abs, dp.nbad, b.part_bytes / 4,
+                       (d.nbad || dp.nbad) ? "FAIL" : "ok");
+                ok &= d.nbad == 0 && dp.nbad == 0;
+            }
+        }
+    }
+    if (reps > 0) {
+        const double gf = 2.0 * c.M * s.C * 27.0 * s.C * 1e-9;
+        const float t_new = time_us([&] { run_new(c, b, false, false, st); }, reps, st);
+        printf("   time new plain  : %7.1f us  (%6.0f TF/s)\n", t_new, gf / t_new * 1e-3);
+        if (do_old && p_conv) { const float t_old = time_us([&] { run_old(c, b, false, false, st); }, reps, st); printf("   time old plain  : %7.1f us  (%6.0f TF/s)\n", t_old, gf / t_old * 1e-3); }
+        if (do_fused && es == 2 && s.C <= 128) {
+            const float tf_new = time_us([&] { run_new(c, b, true, true, st); }, reps, st);
+            printf("   time new fused  : %7.1f us\n", tf_new);
+            if (p_convpw) { const float tf_old = time_us([&] { run_old(c, b, true, true, st); }, reps, st); printf("   time old fused  : %7.1f us\n", tf_old); }
+        }
+    }
+    fflush(stdout);
+    hipFree(b.out); hipFree(b.ws); hipFree(b.ws3); hipFree(b.cnt); hipFree(b.part); free_case(c);
+    return ok;
+}
+
+int main(int argc, char** argv) {
+    std::string lib = argc > 1 ? argv[1] : "magvit2_pytorch_amd/libmv2_hip_exp.so";
+    void* h = dlopen(lib.c_str(), RTLD_NOW);
+    if (!h) { printf("dlopen %s: %s\n", lib.c_str(), dlerror()); return 2; }
+    p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
+    p_conv3 = (conv3_fn)dlsym(h, "mv2_conv3"); p_c3_ws = (ws_fn)dlsym(h, "mv2_conv3_workspace_bytes"); p_c3_cnt = (ws_fn)dlsym(h, "mv2_conv3_counter_bytes");
+    p_c3_tiles = (tiles_fn)dlsym(h, "mv2_conv3_tiles"); p_convpw = (convpw_fn)dlsym(h, "mv2_conv_pw");
+    if (!p_conv3 || !p_c3_ws || !p_c3_cnt || !p_c3_tiles) { printf("missing mv2_conv3 symbols\n"); return 2; }
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+    hipStream_t st; CK(hipStreamCreate(&st));
+    bool ok = true;
+    // small shapes against the CPU reference: ragged tiles, kt = 1/2/3, batch > 1, both dtypes, every channel width
+    const Shape small[] = {{1, 3, 12, 20, 64, 3}, {2, 2, 9, 17, 128, 3}, {1, 4, 16, 16, 256, 3}, {1, 2, 8, 8, 512, 3}, {1, 5, 4, 4, 512, 3},
+                           {1, 1, 20, 36, 64, 1}, {1, 3, 10, 10, 128, 2}, {3, 1, 2, 2, 256, 3}};
+    for (const Shape& s : small) ok &= test_shape(s, 2, true, true, true, 0, st);
+    ok &= test_shape({1, 3, 12, 20, 64, 3}, 4, true, true, false, 0, st);
+    ok &= test_shape({1, 2, 8, 16, 256, 3}, 4, true, true, false, 0, st);
+    // the level shapes of BASELINE configs[1] (B = 1) and configs[2] (B = 4): A/B against the round-1 kernel + timing
+    const Shape levels[] = {{1, 20, 128, 128, 64, 3}, {1, 20, 64, 64, 128, 3}, {1, 20, 32, 32, 256, 3}, {1, 20, 16, 16, 512, 3}, {1, 10, 16, 16, 512, 3}, {1, 5, 16, 16, 512, 3}};
+    for (const Shape& s : levels) ok &= test_shape(s, 2, false, true, true, quick ? 5 : 20, st);
+    if (!quick) {
+        const Shape b4[] = {{4, 20, 128, 128, 64, 3}, {4, 20, 64, 64, 128, 3}, {4, 20, 32, 32, 256, 3}, {4, 20, 16, 16, 512, 3}, {4, 5, 16, 16, 512, 3}};
+        for (const Shape& s : b4) ok &= test_shape(s, 2, false, true, false, 10, st);
+        ok &= test_shape({1, 20, 32, 32, 256, 3}, 4, false, true, false, 5, st);
+    }
+    printf(ok ? "ALL OK\n" : "SOME FAILED\n");
+    return ok ? 0 : 1;
+}
