@@ -126,13 +126,13 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
  * wp3: the same [nsteps][co_pad][128 B] weights as mv2_conv's Wp (step = ((it*3 + ih)*3 + iw) * nchunk + chunk), but each
  *      group of 32 output rows is stored in MFMA-fragment order: [step][co_pad/32][k-slice 4][half 2][row 32][16 B],
  *      where the 16-byte chunk (2*k-slice + half) of row r of the plain layout is meant (pack.py pack_conv3d(frag_major)).
- * Epilogue as mv2_conv (rowscale, bias, act, residual; MV2_STORE_ROWS or MV2_STORE_SHUFFLE).
- * Fused second stage (wp2 != NULL): bf16 only, C_out in {64, 128} (a block then owns every channel of its
- *      positions), no rowscale / residual; wp2 = the pointwise weights packed like any 1x1x1 conv ([C/64][128][128 B]).
+ * Epilogue: v += bias[n]; act (MV2_ACT_NONE or MV2_ACT_ELU); store rows (MV2_STORE_ROWS, out_c >= co).
+ * Fused second stage (wp2 != NULL): bf16 only, C_out = 64 (a workgroup then owns every channel of its positions;
+ *      mv2_conv3_fusable()); wp2 = the pointwise weights packed like any 1x1x1 conv ([1][128][128 B]); act2 NONE or ELU.
  *      se_part (optional, with se_wk / se_bk = SqueezeExcite to_k weight (C) and bias): the kernel also writes the
- *      pooling partials of every spatial tile of every frame in mv2_se_pool's record format
+ *      pooling partials of every 2 x 16 strip of positions of every frame in mv2_se_pool's record format
  *        se_part[(frame * n + j) * (C + 2)] = {max logit, sum exp, exp-weighted channel sums[C]},
- *      n = mv2_conv3_tiles(d, &th, &tw) tiles of th x tw positions per frame, j = tile_row * ceil(W/tw) + tile_col.
+ *      n = mv2_conv3_tiles(d, &th, &tw) strips of th x tw = 2 x 16 positions per frame, j = strip_row * ceil(W/16) + strip_col.
  * Work split: one workgroup per CU walks an equal share of the (tile, chunk, time-tap) list; a tile shared by
  *      several workgroups is combined in-kernel (fp32 partials in `workspace`, a ticket per tile in `counters`, summed
  *      in a fixed order: results are bitwise reproducible).  workspace: mv2_conv3_workspace_bytes(d) bytes, contents
@@ -140,11 +140,12 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
  *      leaves them zero, so one zero-initialised buffer can serve every mv2_conv3 launch of a stream.
  * ------------------------------------------------------------------------------------------- */
 int mv2_conv3_eligible(const mv2_conv_desc* d);
+int mv2_conv3_fusable(const mv2_conv_desc* d);          /* may this descriptor be launched with wp2 != NULL? */
 size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d);
 size_t mv2_conv3_counter_bytes(const mv2_conv_desc* d);
 int mv2_conv3_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w);
 int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp3, const float* bias,
-              const float* rowscale, const void* residual, const void* wp2, const float* bias2, int act2,
+              const void* wp2, const float* bias2, int act2,
               const float* se_wk, float se_bk, float* se_part, void* out, void* workspace, size_t workspace_bytes,
               uint32_t* counters, size_t counter_bytes, void* stream);
 

@@ -22,8 +22,8 @@
 //     requirement).  There is no finish kernel and no second pass over the output.
 // Zero padding in space comes from out-of-range buffer offsets (hardware returns 0).
 #include <algorithm>
+#include <cstdlib>
 #include "conv_common.h"
-#include "conv_fused_pw.h"
 
 namespace {
 
@@ -82,40 +82,53 @@ __device__ __forceinline__ uint32_t worker_of(uint32_t x, uint32_t W, uint32_t G
 }
 __device__ __forceinline__ uint32_t start_of(uint32_t w, uint32_t W, uint32_t G) { return (uint32_t)((uint64_t)w * G / W); }
 
-template <typename E, int BCO, int TH, int TW>
-struct C3Cfg {
-    static constexpr int BPOS = TH * TW;
-    static constexpr int WCO = BCO / 32, WPOS = BPOS / 32;          // per-wave MFMA tiles: the whole block tile
-    static constexpr int NTILE = WCO * WPOS;                          // 16
-    static constexpr int WCO_E = WCO == 4 ? 1 : 2, WPOS_E = WCO == 4 ? 4 : 2;   // tiles a wave owns after the reduce
-    static constexpr int HWD = TW + 2, HR = (TH + 2) * HWD;
-    static constexpr int RPP = 32;                                    // halo rows staged per pass (256 threads / 8)
-    static constexpr int NH = (HR + RPP - 1) / RPP;
-    static constexpr int HALO_BYTES = ((HR * 128 + 255) / 256) * 256;
-    static constexpr int RED_BYTES = 4 * 8 * 4096;                    // cross-wave reduce: [src wave][8 tiles of a round] x 4 KB
-    static constexpr int SLAB_BYTES = BCO * BPOS * 4;
-    static constexpr size_t lds_main = 2 * (size_t)HALO_BYTES;
-    static constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, BPOS>::kBytes;
-    static constexpr size_t lds_pw = std::is_same<E, BF16>::value
-                                         ? ((size_t)StageCfg<BF16, BCO, BPOS>::kBytes + 255) / 256 * 256 + (size_t)(BCO * 2 / 128) * BCO * 128 : 0;
-    static constexpr size_t m1 = lds_main > lds_epi ? lds_main : lds_epi;
-    static constexpr size_t m2 = m1 > lds_pw ? m1 : lds_pw;
-    static constexpr size_t m3 = m2 > (size_t)RED_BYTES ? m2 : (size_t)RED_BYTES;
-    static constexpr size_t kFlagOff = (m3 + 15) / 16 * 16;           // 16-byte scratch word after everything else
-    static constexpr size_t kLds = kFlagOff + 16;
-    static_assert(NTILE == 16 && (WCO == 4 || WCO == 2), "wave tile: 4x4 or 2x8 MFMA tiles");
-    static_assert(kLds <= 160 * 1024, "LDS budget");
+// ---- geometry (one tile class: 64 output channels x 8x16 positions, four waves, two workgroups per CU)
+constexpr int BCO = 64, TH = 8, TW = 16, BPOS = TH * TW;
+constexpr int WCO = BCO / 32, WPOS = BPOS / 32;                       // per-wave MFMA tiles (2 x 4): the whole block tile
+constexpr int HWD = TW + 2, HR = (TH + 2) * HWD;                      // halo: 10 x 18 rows
+constexpr int RPP = 32, NH = (HR + RPP - 1) / RPP;                    // halo rows staged per pass / passes
+constexpr int ROWP = 144;                                             // LDS pitch of a 128-byte halo row (see pbase)
+constexpr int HALO_BYTES = ((HR * ROWP + 255) / 256) * 256;
+constexpr int RED_BYTES = 4 * 4 * 4096;                               // cross-wave reduce round: [src wave][4 tiles] x 4 KB
+constexpr int SLAB_BYTES = BCO * BPOS * 4;
+constexpr int WD = 3;                                                 // weight register sets (prefetch distance in taps)
+constexpr int HWT = 5;                                                // tap at which the prefetched halo goes into the idle image
+
+template <typename E, bool FUSED>
+struct C3Lds {
+    static constexpr int PITCH = BCO * E::kBytes + 16;                // row of a wave-private epilogue tile
+    static constexpr int PRIV = 32 * PITCH + 128;                     // 32 positions + 32 floats of pooling scratch
+    static constexpr int kMain = 2 * HALO_BYTES > RED_BYTES ? 2 * HALO_BYTES : RED_BYTES;
+    static_assert(4 * PRIV <= kMain, "wave-private epilogue tiles live in the reduce region");
+    static constexpr int kBias = kMain;                               // 64 fp32 bias values of the segment's channel tile
+    static constexpr int kConst2 = kBias + 256;                       // fused stage: bias2[64], se_wk[64] (fp32), staged once
+    static constexpr int kW2 = kConst2 + (FUSED ? 512 : 0);           // fused stage: 64 x 64 pointwise weights, staged once per workgroup
+    static constexpr int kFlag = kW2 + (FUSED ? BCO * 128 : 0);
+    static constexpr int kLds = kFlag + 16;
+    static_assert(kLds <= 80 * 1024, "two workgroups per CU");
 };
 
 }  // namespace
 
-template <typename E, int BCO, int TH, int TW>
-__global__ __launch_bounds__(256, 1) void conv3_kernel(const ConvParams p) {
-    typedef C3Cfg<E, BCO, TH, TW> Cfg;
-    constexpr int BPOS = Cfg::BPOS, WCO = Cfg::WCO, WPOS = Cfg::WPOS, WCO_E = Cfg::WCO_E, WPOS_E = Cfg::WPOS_E;
-    constexpr int HWD = Cfg::HWD, HR = Cfg::HR, RPP = Cfg::RPP, NH = Cfg::NH, HALO_BYTES = Cfg::HALO_BYTES;
-    constexpr int NT = 256;
-    constexpr int HWT = 3;                          // tap at which the prefetched halo is written into the idle image
+#ifdef MV2_EXPERIMENTS
+// phase clocks (s_memtime) per workgroup: [0] prologue [1] tap loop [2] cross-wave reduce [3] partial/ticket [4] epilogue
+// [5] segments [6] groups [7] whole kernel; written to g_conv3_prof when tools/k3_bench asks for it
+__device__ unsigned long long* g_conv3_prof = nullptr;
+#define C3_PROF_DECL unsigned long long pf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_ = __builtin_amdgcn_s_memtime(); const unsigned long long pt0_ = pt_;
+#define C3_PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
+#define C3_PROF_COUNT(k, v) pf_[k] += (v);
+#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; for (int i_ = 0; i_ < 8; ++i_) g_conv3_prof[(size_t)blockIdx.x * 8 + i_] = pf_[i_]; }
+#else
+#define C3_PROF_DECL
+#define C3_PROF(k)
+#define C3_PROF_COUNT(k, v)
+#define C3_PROF_END
+#endif
+
+template <typename E, bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
+    typedef C3Lds<E, FUSED> L;
+    static_assert(!FUSED || std::is_same<E, BF16>::value, "fused second stage: bf16 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const mv2_conv_desc& d = p.d;
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void conv3_kernel(const ConvParams p) {
     const int kt = d.kt;
 
     // ---- this block's range of groups (XCD-aware: the blocks of one XCD walk one contiguous eighth of the list,
-    // i.e. one co tile's weights where there are several: their 3.4 MB at C = 512 stay in that XCD's L2)
+    // i.e. few co tiles' weights: they stay in that XCD's L2)
     const uint32_t NW = gridDim.x, G = p.gtot;
     uint32_t bid = blockIdx.x;
     {
@@ -139,26 +152,121 @@ __global__ __launch_bounds__(256, 1) void conv3_kernel(const ConvParams p) {
     const uint32_t row_bytes = (uint32_t)d.Ci * E::kBytes;
     const uint32_t frame_bytes = (uint32_t)((int64_t)H * W_ * d.Ci * E::kBytes);
     const uint32_t w_step = (uint32_t)d.co_pad * 128u;
+    const uint32_t tapstride = (uint32_t)p.nchunk * w_step;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.w_bytes, 0x00020000);
-    const uint32_t lds_wr = (uint32_t)r0 * 128u + (uint32_t)((c ^ ((r0 >> 1) & 7)) << 4);
-    const uint32_t ck = (uint32_t)(wave * 2 + hi);          // this lane's 16-byte chunk of every 128-byte row
-    // halo row of this lane's positions for the (dh = -1, dw = -1) tap
-    int prow0[WPOS];
+    // bias: zero-length descriptor when absent -> every load returns 0
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : (const float*)p.wp), 0,
+                                                                          p.bias ? (uint32_t)d.co_pad * 4u : 0u, 0x00020000);
+    // Halo image: row r of the 10 x 18 halo at r * 144 bytes (128 data + 16 pad).  A 32-lane MFMA operand reads 16 bytes
+    // per lane at (row, this wave's chunk): the ds_read_b128 service groups of 16 lanes hit 16 distinct 16-byte slots of
+    // the 256-byte bank row iff their rows are distinct mod 16 (9 = 144/16 is odd) -> conflict free with pos_of()'s
+    // rotation, and the nine taps are nine IMMEDIATE offsets from one per-lane address (no per-tap VALU).
+    const uint32_t lds_wr = (uint32_t)r0 * ROWP + (uint32_t)c * 16u;
+    uint32_t pbase[WPOS];
 #pragma unroll
     for (int bb = 0; bb < WPOS; ++bb) {
         int ph, pw; pos_of<TW>(bb * 32 + l31, ph, pw);
-        prow0[bb] = ph * HWD + pw;
+        pbase[bb] = (uint32_t)(ph * HWD + pw) * ROWP + (uint32_t)(wave * 2 + hi) * 16u;
+    }
+    if constexpr (FUSED) {      // pointwise weights -> LDS once (swizzled rows); visible after the first segment's barrier
+        for (int q = tid; q < BCO * 8; q += 256) {
+            const int row = q >> 3, ch = q & 7;
+            *(i32x4*)(smem + L::kW2 + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = *(const i32x4*)((const char*)p.wp2 + (size_t)row * 128 + ch * 16);
+        }
+        if (tid < 16) *(f32x4*)(smem + L::kConst2 + tid * 16) = p.bias2 ? *(const f32x4*)(p.bias2 + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (tid < 32) *(f32x4*)(smem + L::kConst2 + tid * 16) = p.se_wk ? *(const f32x4*)(p.se_wk + (tid - 16) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (uint32_t x = x0; x < x1;) {
-        const TileInfo ti = decode_group(p, x);
-        const uint32_t xe = min(x1, ti.G0 + ti.ng);
-        const int gb = (int)(x - ti.G0), ge = (int)(xe - ti.G0);
-        const int v = ti.v, t = ti.t, b = ti.b;
-        const int h0 = ti.thi * TH, w0 = ti.twi * TW;
-        const int n0 = ti.co_tile * BCO;
+    // ---- per-segment state: scalars of the tile + the incremental (chunk, time tap) walk over its groups
+    struct Seg {
+        TileInfo ti; uint32_t x, xe; int gb, ge;
+        uint32_t hmask, hw_base, w_off0;
+        int cur_chunk, cur_it, nxt_chunk, nxt_it;
+        uint32_t cur_wb, nxt_wb;
+    };
+    i32x4 hreg[NH];
+    i32x4 wset[WD][WCO], pset[3][WPOS];
+    i32x4 bias_v;                                       // lanes 0..15 of the block: the segment's 64 bias values (part of the prefetch stream)
 
+    auto advance = [&](const Seg& S, int& chunk, int& it) {
+        const bool wrap = it + 1 == kt;
+        it = wrap ? kt - S.ti.v : it + 1;
+        chunk += wrap ? 1 : 0;
+    };
+    auto wbase_of = [&](int chunk, int it) { return (uint32_t)(it * 9 * p.nchunk + chunk) * w_step; };
+    auto make_seg = [&](uint32_t x) {
+        Seg S;
+        S.ti = decode_group(p, x);
+        S.x = x; S.xe = min(x1, S.ti.G0 + S.ti.ng);
+        S.gb = (int)(x - S.ti.G0); S.ge = (int)(S.xe - S.ti.G0);
+        const int h0 = S.ti.thi * TH, w0 = S.ti.twi * TW;
+        S.hmask = 0;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hr = r0 + RPP * i;
+            if (hr < HR) {
+                const int hy = hr / HWD, hx = hr - hy * HWD;
+                const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
+                if ((unsigned)hin < (unsigned)H && (unsigned)win < (unsigned)W_) S.hmask |= 1u << i;
+            }
+        }
+        S.hw_base = (uint32_t)(((int64_t)(h0 - 1) * W_ + (w0 - 1)) * (int64_t)row_bytes);
+        // weights: this wave's fragment of co-group a lives at  step * w_step + ((n0/32 + a) * 4 + wave) * 1024 + lane * 16
+        S.w_off0 = (uint32_t)(((S.ti.co_tile * (BCO / 32)) * 4 + wave) * 1024 + lane * 16);
+        // (chunk, time tap) of group gi of the tile: chunk-major; `cur` = group gi, `nxt` = gi + 1, clamped to the last group of
+        // the segment (prefetches past the end re-read valid, cached addresses and are never consumed)
+        const int v = S.ti.v;
+        S.cur_chunk = v == 1 ? S.gb : (v == 2 ? (S.gb >> 1) : S.gb / 3);
+        S.cur_it = (kt - v) + (S.gb - S.cur_chunk * v);
+        S.nxt_chunk = S.cur_chunk; S.nxt_it = S.cur_it;
+        if (S.gb + 1 < S.ge) advance(S, S.nxt_chunk, S.nxt_it);
+        S.cur_wb = wbase_of(S.cur_chunk, S.cur_it); S.nxt_wb = wbase_of(S.nxt_chunk, S.nxt_it);
+        return S;
+    };
+    // every load is unconditional in instruction count (spatial padding -> out-of-range offset -> zeros, no traffic)
+    auto issue_halo = [&](const Seg& S, int chunk, int it) {
+        const int t_in = S.ti.t + it - d.pt;                        // >= 0 by construction of the group list
+        const uint32_t base = (uint32_t)(((int64_t)S.ti.b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + S.hw_base;
+        int r0_ = r0;
+        asm volatile("" : "+v"(r0_));          // recompute the six row offsets per group: cheaper than six live registers (VGPR budget)
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hr = r0_ + RPP * i;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const bool ok = (S.hmask >> i) & 1u;
+            const uint32_t vo = ok ? base + (uint32_t)(hy * W_ + hx) * row_bytes : p.in_bytes;
+            hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
+        }
+    };
+    auto write_halo = [&](char* img) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hreg[i];
+    };
+    auto issue_w1 = [&](const Seg& S, uint32_t so, int a, i32x4& dst) {
+        dst = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)S.w_off0, (int)(so + (uint32_t)(a * 4096)), 0);
+    };
+    auto issue_first = [&](const Seg& S) {     // halo of the segment's first group + its first WD weight taps + its bias values
+        issue_halo(S, S.cur_chunk, S.cur_it);
+        bias_v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(tid < 16 ? (uint32_t)(S.ti.co_tile * BCO + tid * 4) * 4u : 0xfffffff0u), 0, 0);
+#pragma unroll
+        for (int q = 0; q < WD; ++q)
+#pragma unroll
+            for (int a = 0; a < WCO; ++a) issue_w1(S, S.cur_wb + (uint32_t)q * tapstride, a, wset[q][a]);
+    };
+    auto read_p = [&](uint32_t img, int tp, auto set_c) {     // img: LDS byte offset of the halo image
+        constexpr int SET = decltype(set_c)::value;
+        const int toff = ((tp / 3) * HWD + (tp % 3)) * ROWP;
+#pragma unroll
+        for (int bb = 0; bb < WPOS; ++bb) pset[SET][bb] = *(const i32x4*)(smem + (pbase[bb] + img) + toff);
+    };
+
+    C3_PROF_DECL
+    Seg S = make_seg(x0);
+    issue_first(S);
+    for (;;) {
+        C3_PROF(4)
         f32x16 acc[WCO][WPOS];
 #pragma unroll
         for (int a = 0; a < WCO; ++a)
@@ -166,186 +274,119 @@ __global__ __launch_bounds__(256, 1) void conv3_kernel(const ConvParams p) {
             for (int bb = 0; bb < WPOS; ++bb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
-
-        // ---- halo gather state of this tile
-        uint32_t hmask = 0;
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-            const int hr = r0 + RPP * i;
-            if (hr < HR) {
-                const int hy = hr / HWD, hx = hr - hy * HWD;
-                const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
-                if ((unsigned)hin < (unsigned)H && (unsigned)win < (unsigned)W_) hmask |= 1u << i;
-            }
-        }
-        const uint32_t hw_base = (uint32_t)(((int64_t)(h0 - 1) * W_ + (w0 - 1)) * (int64_t)row_bytes);
-        // weights: this wave's fragment of co-group a lives at  step * w_step + ((n0/32 + a) * 4 + wave) * 1024 + lane * 16
-        const uint32_t w_off0 = (uint32_t)(((n0 >> 5) * 4 + wave) * 1024 + lane * 16);
-
-        i32x4 hreg[NH];
-        i32x4 wset[3][WCO], pset[3][WPOS];
-
-        // (chunk, time tap) of the groups of this tile: chunk-major list, advanced incrementally in scalar registers
-        // (no per-tap division, no branches).  `cur` = group gi, `nxt` = group gi + 1 (clamped to the last group of
-        // the segment: the prefetches past the end re-read valid, already cached addresses and are never consumed).
-        int cur_chunk = v == 1 ? gb : (v == 2 ? (gb >> 1) : gb / 3);
-        int cur_it = (kt - v) + (gb - cur_chunk * v);
-        auto advance = [&](int& chunk, int& it) {
-            const bool wrap = it + 1 == kt;
-            it = wrap ? kt - v : it + 1;
-            chunk += wrap ? 1 : 0;
-        };
-        int nxt_chunk = cur_chunk, nxt_it = cur_it;
-        if (gb + 1 < ge) advance(nxt_chunk, nxt_it);
-        const uint32_t tapstride = (uint32_t)p.nchunk * w_step;
-        auto wbase_of = [&](int chunk, int it) { return (uint32_t)(it * 9 * p.nchunk + chunk) * w_step; };
-        auto issue_halo = [&](int chunk, int it) {
-            const int t_in = t + it - d.pt;                        // >= 0 by construction of the group list
-            const uint32_t base = (uint32_t)(((int64_t)b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + hw_base;
-#pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                const int hr = r0 + RPP * i;
-                const int hy = hr / HWD, hx = hr - hy * HWD;
-                const bool ok = (hmask >> i) & 1u;
-                const uint32_t vo = ok ? base + (uint32_t)(hy * W_ + hx) * row_bytes : p.in_bytes;     // padding: out of range -> zeros
-                hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
-            }
-        };
-        auto write_halo = [&](char* img) {
-#pragma unroll
-            for (int i = 0; i < NH; ++i)
-                if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * 128) = hreg[i];
-        };
-        auto issue_w = [&](uint32_t wbase, int tp, auto set_c) {
-            constexpr int SET = decltype(set_c)::value;
-            const uint32_t so = wbase + (uint32_t)tp * tapstride;
-#pragma unroll
-            for (int a = 0; a < WCO; ++a) wset[SET][a] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)w_off0, (int)(so + (uint32_t)(a * 4096)), 0);
-        };
-        auto read_p = [&](const char* img, int tp, auto set_c) {
-            constexpr int SET = decltype(set_c)::value;
-            const int toff = (tp / 3) * HWD + (tp % 3);
-#pragma unroll
-            for (int bb = 0; bb < WPOS; ++bb) {
-                int pr_ = prow0[bb];
-                asm volatile("" : "+v"(pr_));       // keep the unrolled taps from hoisting all their LDS addresses (VGPR budget)
-                const int pr = pr_ + toff;
-                pset[SET][bb] = *(const i32x4*)(img + (uint32_t)pr * 128u + ((ck ^ (uint32_t)((pr >> 1) & 7)) << 4));
-            }
-        };
-
-        // ---- prologue: halo image of the first group, weights of taps 0..2, fragments of tap 0
-        uint32_t cur_wb = wbase_of(cur_chunk, cur_it), nxt_wb = wbase_of(nxt_chunk, nxt_it);
-        issue_halo(cur_chunk, cur_it);
-        issue_w(cur_wb, 0, IC<0>{});
-        issue_w(cur_wb, 1, IC<1>{});
-        issue_w(cur_wb, 2, IC<2>{});
         write_halo(smem);
         __syncthreads();
-        read_p(smem, 0, IC<0>{});
+        read_p(0u, 0, IC<0>{});
+        C3_PROF(0)
 
-        // one tap: sets TP % 3 hold W(gi, TP) (requested three taps ago) and P(gi, TP) (read one tap ago)
-        auto tap = [&](const char* img, char* other, auto tp_c) {
+        // one tap.  Weights of tap TP live in set TP % WD, requested WD taps ago; pset[TP % 3] holds the position fragments,
+        // read one tap ago.  The reload of a weight fragment is issued right behind the last MFMA that reads it, so loads,
+        // LDS reads and MFMAs interleave instead of forming phases.
+        auto tap = [&](uint32_t img, uint32_t other, auto tp_c) {
             constexpr int TP = decltype(tp_c)::value;
-            constexpr int SET = TP % 3, NSET = (TP + 1) % 3;
-            if constexpr (TP == 0) issue_halo(nxt_chunk, nxt_it);
+            constexpr int SET = TP % 3, NSET = (TP + 1) % 3, WS = TP % WD;
+            if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it);
             if constexpr (TP == 8) __syncthreads();       // the next group's image is complete; this one has no reader left
             if constexpr (TP < 8) read_p(img, TP + 1, IC<NSET>{});
             else read_p(other, 0, IC<NSET>{});
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);            // keep the fragment reads of the NEXT tap at the top (the scheduler sinks them to their use)
+            const uint32_t so = (TP + WD < 9 ? S.cur_wb + (uint32_t)(TP + WD) * tapstride : S.nxt_wb + (uint32_t)(TP + WD - 9) * tapstride);
 #pragma unroll
-            for (int a = 0; a < WCO; ++a)
+            for (int a = 0; a < WCO; ++a) {
 #pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(wset[SET][a], pset[SET][bb], acc[a][bb]);
-            if constexpr (TP + 3 < 9) issue_w(cur_wb, TP + 3, IC<SET>{});
-            else issue_w(nxt_wb, TP + 3 - 9, IC<SET>{});
-            if constexpr (TP == HWT) write_halo(other);   // image of group gi-1: its last reader passed the previous barrier
+                for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(wset[WS][a], pset[SET][bb], acc[a][bb]);
+                issue_w1(S, so, a, wset[WS][a]);
+            }
+            if constexpr (TP == HWT) write_halo(smem + other);   // image of group gi-1: its last reader passed the previous barrier
             __builtin_amdgcn_sched_barrier(0);
         };
-        for (int gi = gb; gi < ge; ++gi) {
-            const int par = (gi - gb) & 1;
-            const char* img = smem + par * HALO_BYTES;
-            char* other = smem + (par ^ 1) * HALO_BYTES;
+        for (int gi = S.gb; gi < S.ge; ++gi) {
+            const int par = (gi - S.gb) & 1;
+            const uint32_t img = (uint32_t)(par * HALO_BYTES), other = (uint32_t)((par ^ 1) * HALO_BYTES);
             tap(img, other, IC<0>{}); tap(img, other, IC<1>{}); tap(img, other, IC<2>{});
             tap(img, other, IC<3>{}); tap(img, other, IC<4>{}); tap(img, other, IC<5>{});
             tap(img, other, IC<6>{}); tap(img, other, IC<7>{}); tap(img, other, IC<8>{});
-            cur_chunk = nxt_chunk; cur_it = nxt_it; cur_wb = nxt_wb;
-            if (gi + 2 < ge) { advance(nxt_chunk, nxt_it); nxt_wb = wbase_of(nxt_chunk, nxt_it); }
+            S.cur_wb = S.nxt_wb;
+            if (gi + 2 < S.ge) { advance(S, S.nxt_chunk, S.nxt_it); S.nxt_wb = wbase_of(S.nxt_chunk, S.nxt_it); }
         }
+        if (tid < 16) *(i32x4*)(smem + L::kBias + tid * 16) = bias_v;     // epilogue reads bias from LDS: no global load behind the next prefetch
         __syncthreads();                                    // halo images are dead: LDS becomes the reduce region
+        C3_PROF(1)
+        C3_PROF_COUNT(5, 1)
+        C3_PROF_COUNT(6, (unsigned long long)(S.ge - S.gb))
 
-        // ---- cross-wave reduce: wave w ends up with 4 of the 16 MFMA tiles, summed over the 4 k-slices in wave order.
-        // Two rounds of 8 tiles: every wave drops its 8 partial tiles of the round into LDS (straight from the
-        // accumulator registers), then reads the four partials of the two tiles it owns.  Ownership only enters
-        // through an LDS address, so no accumulator is indexed at run time.
-        //   BCO = 128: round(a, b) = b >> 1, slot j = 2 a + (b & 1),  owner = a       -> acc_e[0][2 rnd + k]
-        //   BCO =  64: round(a, b) = b & 1,  slot j = 2 (b >> 1) + a, owner = b >> 1  -> acc_e[k][rnd]
-        f32x16 acc_e[WCO_E][WPOS_E];
+        // Lane-derived values of the code below are re-derived from an opaque copy of the lane id: otherwise loop-invariant
+        // code motion hoists every address of the reduce / ticket / epilogue to kernel entry, they are spilled around the tap loop,
+        // and each scratch reload waits vmcnt(0) behind the stores and prefetches in flight (measured: ~10k clocks per tile).
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int hi_o = lane_o >> 5, l31_o = lane_o & 31;
+        // ---- cross-wave reduce: wave w ends up with BOTH channel tiles of position tile w (all 64 channels of its 32
+        // positions), summed over the 4 k-slices in wave order.  Two rounds (round = channel tile a): every wave drops its four
+        // partial tiles of the round into LDS (straight from the accumulator registers), then reads the four partials of the
+        // one tile it owns.  Ownership only enters through an LDS address: no accumulator is indexed at run time.
+        f32x16 acc_e[WCO];
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
+        for (int a = 0; a < WCO; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < WPOS; ++bb) {
+                char* dst = smem + (wave * 4 + bb) * 4096 + lane_o * 16;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 vv = {acc[a][bb][4 * r4], acc[a][bb][4 * r4 + 1], acc[a][bb][4 * r4 + 2], acc[a][bb][4 * r4 + 3]};
+                    *(f32x4*)(dst + r4 * 1024) = vv;
+                }
+            }
+            __syncthreads();
+            f32x16 sum;
+#pragma unroll
+            for (int src = 0; src < 4; ++src) {
+                const char* sp = smem + (src * 4 + wave) * 4096 + lane_o * 16;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 vv = *(const f32x4*)(sp + r4 * 1024);
+                    if (src == 0) { sum[4 * r4] = vv[0]; sum[4 * r4 + 1] = vv[1]; sum[4 * r4 + 2] = vv[2]; sum[4 * r4 + 3] = vv[3]; }
+                    else { sum[4 * r4] += vv[0]; sum[4 * r4 + 1] += vv[1]; sum[4 * r4 + 2] += vv[2]; sum[4 * r4 + 3] += vv[3]; }
+                }
+            }
+            acc_e[a] = sum;
+            __syncthreads();
+        }
+        // ---- the next segment's first halo image and weight taps start their flight now (the accumulators are dead, the
+        // registers of the loads are free until the next tap loop): they land under this segment's ticket / epilogue
+        const bool has_next = S.xe < x1;
+        Seg N = S;
+        if (has_next) { N = make_seg(S.xe); issue_first(N); }
+        C3_PROF(2)
+
+        // ---- a tile cut by a range boundary: publish the partial, take a ticket, the last arriver sums every part.
+        // Slab stores are write-through (sc1) and the last arriver reads with sc1 loads: no L2 write-back / invalidate
+        // fence on either side (cdna_hip_programming.md §5 "in-launch split-K reduction", the write-through form).
+        const TileInfo& ti = S.ti;
+        const bool partial = S.gb != 0 || (uint32_t)S.ge != ti.ng;
+        bool finish = true;
+        if (partial) {
+            constexpr int WSLAB = SLAB_BYTES / 4;     // bytes per wave inside a slab
+            const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
+            const uint32_t slot = 2 * bid + (S.x == x0 ? 0u : 1u);
+            const uint32_t soff = slot * (uint32_t)SLAB_BYTES + (uint32_t)wave * WSLAB + (uint32_t)lane_o * 16u;
 #pragma unroll
             for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) {
-                    const int tr = WCO == 4 ? (bb >> 1) : (bb & 1);
-                    const int j = WCO == 4 ? (2 * a + (bb & 1)) : (2 * (bb >> 1) + a);
-                    if (tr != rnd) continue;
-                    char* dst = smem + (wave * 8 + j) * 4096 + lane * 16;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 vv = {acc[a][bb][4 * r4], acc[a][bb][4 * r4 + 1], acc[a][bb][4 * r4 + 2], acc[a][bb][4 * r4 + 3]};
-                        *(f32x4*)(dst + r4 * 1024) = vv;
-                    }
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    i32x4 vv = {__float_as_int(acc_e[a][4 * r4]), __float_as_int(acc_e[a][4 * r4 + 1]),
+                                __float_as_int(acc_e[a][4 * r4 + 2]), __float_as_int(acc_e[a][4 * r4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(vv, rs_ws, (int)(soff + (uint32_t)((a * 4 + r4) * 1024)), 0, 16 /* sc1 */);
                 }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                f32x16 s;
-#pragma unroll
-                for (int src = 0; src < 4; ++src) {
-                    const char* sp = smem + (src * 8 + wave * 2 + k) * 4096 + lane * 16;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 vv = *(const f32x4*)(sp + r4 * 1024);
-                        if (src == 0) { s[4 * r4] = vv[0]; s[4 * r4 + 1] = vv[1]; s[4 * r4 + 2] = vv[2]; s[4 * r4 + 3] = vv[3]; }
-                        else { s[4 * r4] += vv[0]; s[4 * r4 + 1] += vv[1]; s[4 * r4 + 2] += vv[2]; s[4 * r4 + 3] += vv[3]; }
-                    }
-                }
-                if constexpr (WCO == 4) acc_e[0][2 * rnd + k] = s; else acc_e[k][rnd] = s;
-            }
-            __syncthreads();
-        }
-        const int wco_e = WCO == 4 ? wave : 0, wpos_e = WCO == 4 ? 0 : wave;
-
-        // ---- a tile cut by a range boundary: publish the partial, take a ticket, the last arriver sums every part
-        const bool partial = gb != 0 || (uint32_t)ge != ti.ng;
-        bool finish = true;
-        if (partial) {
-            const uint32_t slot = 2 * bid + (x == x0 ? 0u : 1u);
-            char* slab = (char*)p.ws + (size_t)slot * Cfg::SLAB_BYTES + (size_t)wave * 16384 + lane * 16;
-#pragma unroll
-            for (int a = 0; a < WCO_E; ++a)
-#pragma unroll
-                for (int bb = 0; bb < WPOS_E; ++bb)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 vv = {acc_e[a][bb][4 * r4], acc_e[a][bb][4 * r4 + 1], acc_e[a][bb][4 * r4 + 2], acc_e[a][bb][4 * r4 + 3]};
-                        *(f32x4*)(slab + ((a * WPOS_E + bb) * 4 + r4) * 1024) = vv;
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket
             __syncthreads();
             const uint32_t w_first = worker_of(ti.G0, NW, G), w_last = worker_of(ti.G0 + ti.ng - 1, NW, G);
             const uint32_t nparts = w_last - w_first + 1;
-            uint32_t* flag = (uint32_t*)(smem + Cfg::kFlagOff);
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t* flag = (uint32_t*)(smem + L::kFlag);
+            if (wave == 0 && lane_o == 0) {
                 const uint32_t ticket = __hip_atomic_fetch_add(p.counters + ti.L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t last = ticket == nparts - 1 ? 1u : 0u;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(p.counters + ti.L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                }
+                if (last) __hip_atomic_store(p.counters + ti.L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
                 *flag = last;
             }
             __syncthreads();
@@ -353,84 +394,161 @@ __global__ __launch_bounds__(256, 1) void conv3_kernel(const ConvParams p) {
             if (finish) {
                 const uint32_t s_first = start_of(w_first, NW, G);
 #pragma unroll
-                for (int a = 0; a < WCO_E; ++a)
+                for (int a = 0; a < WCO; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < WPOS_E; ++bb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc_e[a][bb][r] = 0.f;
-                for (uint32_t pi = 0; pi < nparts; ++pi) {
+                    for (int r = 0; r < 16; ++r) acc_e[a][r] = 0.f;
+                auto slab_off = [&](uint32_t pi) {
                     const uint32_t wi = w_first + pi;
                     const uint32_t sl = 2 * wi + ((pi == 0 && s_first < ti.G0) ? 1u : 0u);
-                    const char* src = (const char*)p.ws + (size_t)sl * Cfg::SLAB_BYTES + (size_t)wave * 16384 + lane * 16;
+                    return sl * (uint32_t)SLAB_BYTES + (uint32_t)wave * WSLAB + (uint32_t)lane_o * 16u;
+                };
+                // parts are summed in part order (bitwise reproducible); two parts' loads are in flight together
+                for (uint32_t pi = 0; pi < nparts; pi += 2) {
+                    const bool two = pi + 1 < nparts;
+                    const uint32_t so0 = slab_off(pi), so1 = two ? slab_off(pi + 1) : p.ws_bytes;     // odd tail: out of range -> zeros
+                    i32x4 v0[WCO * 4], v1[WCO * 4];
 #pragma unroll
-                    for (int a = 0; a < WCO_E; ++a)
+                    for (int q = 0; q < WCO * 4; ++q) v0[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (int)(so0 + (uint32_t)(q * 1024)), 0, 16 /* sc1 */);
 #pragma unroll
-                        for (int bb = 0; bb < WPOS_E; ++bb)
+                    for (int q = 0; q < WCO * 4; ++q) v1[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_ws, (int)(so1 + (uint32_t)(q * 1024)), 0, 16 /* sc1 */);
 #pragma unroll
-                            for (int r4 = 0; r4 < 4; ++r4) {
-                                const f32x4 vv = *(const f32x4*)(src + ((a * WPOS_E + bb) * 4 + r4) * 1024);
-                                acc_e[a][bb][4 * r4] += vv[0]; acc_e[a][bb][4 * r4 + 1] += vv[1];
-                                acc_e[a][bb][4 * r4 + 2] += vv[2]; acc_e[a][bb][4 * r4 + 3] += vv[3];
-                            }
+                    for (int q = 0; q < WCO * 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc_e[q >> 2][4 * (q & 3) + j] += __int_as_float(v0[q][j]);
+#pragma unroll
+                    for (int q = 0; q < WCO * 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc_e[q >> 2][4 * (q & 3) + j] += __int_as_float(v1[q][j]);
                 }
             }
-            __syncthreads();                                // the flag word is free again
+            // no barrier: the flag word is rewritten only after the next segment's barriers
         }
+        C3_PROF(3)
 
-        // ---- epilogue of a finished tile
+        // ---- epilogue of a finished tile: wave-private (this wave owns every channel of its 32 positions), no block barrier.
+        // acc_e[a][4 g + j] = channel a*32 + 8 g + 4 hi + j of position l31 of the wave's position tile.
         if (finish) {
-            const int64_t frame_row0 = ((int64_t)b * T + t) * H;
-            auto row_of = [&](int lp) -> int64_t {
-                int ph, pw; pos_of<TW>(lp, ph, pw);
-                const bool ok = (h0 + ph) < H && (w0 + pw) < W_;
-                return ok ? (frame_row0 + (h0 + ph)) * W_ + (w0 + pw) : p.M;
+            char* priv = smem + wave * L::PRIV;
+            const int h0 = ti.thi * TH, w0 = ti.twi * TW;
+            const int64_t frame_row0 = ((int64_t)ti.b * T + ti.t) * H;
+            const int n0 = ti.co_tile * BCO;
+            auto put_tile = [&](f32x16 (&v16)[WCO], int bias_off, bool elu) {     // bias_off: LDS offset of 64 fp32 bias values
+#pragma unroll
+                for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = a * 32 + 8 * g + 4 * hi_o;
+                        const f32x4 bv = *(const f32x4*)(smem + bias_off + col * 4);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = v16[a][4 * g + j] + bv[j];
+                            const float e = Act<E>::elu(fminf(xv, 0.f));
+                            v[j] = (elu && xv < 0.f) ? e : xv;
+                        }
+                        lds_put4<E>(priv + l31_o * L::PITCH + col * E::kBytes, v);
+                    }
             };
-            bool done = false;
-            if constexpr (std::is_same<E, BF16>::value) {
-                if (p.wp2) {       // fused 1x1x1 conv + activation (+ SqueezeExcite pooling partials); one co tile by construction
-                    const int64_t tile_index = (((int64_t)b * T + t) * p.tiles_h + ti.thi) * p.tiles_w + ti.twi;
-                    fused_pointwise_epilogue<BCO, BPOS, WCO_E, WPOS_E, NT>(p, smem, acc_e, wco_e, wpos_e, tid, tile_index, row_of);
-                    done = true;
+            put_tile(acc_e, L::kBias, d.act == MV2_ACT_ELU);
+            if constexpr (FUSED) {
+                // second GEMM out of LDS: out[co][pos] = sum_k W2[co][k] * tile[pos][k]; K = 64 = one 128-byte step
+#pragma unroll
+                for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_e[a][r] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t swz = (uint32_t)((l31_o >> 1) & 7);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint32_t ck = (uint32_t)(ks * 2 + hi_o);
+                    const i32x4 fp = *(const i32x4*)(priv + l31_o * L::PITCH + ck * 16);
+#pragma unroll
+                    for (int a = 0; a < WCO; ++a) {
+                        const i32x4 fw = *(const i32x4*)(smem + L::kW2 + (a * 32 + l31_o) * 128 + ((ck ^ swz) << 4));
+                        Mma<E>::run(fw, fp, acc_e[a]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                put_tile(acc_e, L::kConst2, p.act2 == MV2_ACT_ELU);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // whole rows out: 8 lanes per row (128 B bf16 / 16 lanes at fp32), 16 bytes per lane
+            constexpr int CPR = BCO * E::kBytes / 16, RPI = 64 / CPR;            // chunks per row, rows per instruction
+            {
+                const int ch = lane_o % CPR, rr = lane_o / CPR;
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) {
+                    const int row = rr + i * RPI;
+                    int ph, pw; pos_of<TW>(wave * 32 + row, ph, pw);
+                    const bool ok = (h0 + ph) < H && (w0 + pw) < W_ && (n0 + ch * E::kVec) < d.co;
+                    if (ok) {
+                        const int64_t m = (frame_row0 + (h0 + ph)) * W_ + (w0 + pw);
+                        *(i32x4*)((char*)p.out + (m * d.out_c + n0 + ch * E::kVec) * E::kBytes) = *(const i32x4*)(priv + row * L::PITCH + ch * 16);
+                    }
                 }
             }
-            if (!done) {
-                if (stage_ok(p)) {
-                    staged_epilogue<E, BCO, BPOS, WCO_E, WPOS_E, NT>(p, smem, acc_e, n0, wco_e, wpos_e, tid, row_of);
-                } else {
-                    const int nbase = n0 + wco_e * 32 * WCO_E;
+            if constexpr (FUSED) {
+                if (p.se_part) {
+                    // SqueezeExcite pooling partial of this wave's 2 x 16 strip of positions (reference SqueezeExcite.forward
+                    // M:226-231; mv2_se_pool's record {max logit, sum exp, exp-weighted channel sums}), from the bf16 tile in LDS
+                    float* ev = (float*)(priv + 32 * L::PITCH);
+                    const int row = lane_o >> 1, half = lane_o & 1;
+                    float dot = 0.f;
 #pragma unroll
-                    for (int a = 0; a < WCO_E; ++a)
+                    for (int c8 = 0; c8 < 4; ++c8) {
+                        float xv[8];
+                        Chunk<E>::unpack(*(const i32x4*)(priv + row * L::PITCH + (half * 32 + c8 * 8) * 2), xv);
+                        const f32x4 w0v = *(const f32x4*)(smem + L::kConst2 + 256 + (half * 32 + c8 * 8) * 4),
+                                    w1v = *(const f32x4*)(smem + L::kConst2 + 256 + (half * 32 + c8 * 8 + 4) * 4);
 #pragma unroll
-                        for (int bb = 0; bb < WPOS_E; ++bb) {
-                            const int64_t m = row_of(wpos_e * 32 * WPOS_E + bb * 32 + l31);
+                        for (int k = 0; k < 4; ++k) dot += xv[k] * w0v[k];
 #pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                float vv[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) vv[j] = acc_e[a][bb][4 * gq + j];
-                                epi_store4<E>(p, m, nbase + a * 32 + 8 * gq + 4 * hi, vv);
-                            }
-                        }
+                        for (int k = 0; k < 4; ++k) dot += xv[4 + k] * w1v[k];
+                    }
+                    dot += __shfl_xor(dot, 1, 64);
+                    int ph, pw; pos_of<TW>(wave * 32 + row, ph, pw);
+                    const bool valid = (h0 + ph) < H && (w0 + pw) < W_;
+                    const float logit = valid ? dot + p.se_bk : -INFINITY;
+                    const float mx = wave_max(logit);
+                    const float e = (valid && half == 0) ? expf(logit - mx) : 0.f;
+                    const float sw = wave_sum(e);
+                    if (half == 0) ev[row] = e;
+                    __builtin_amdgcn_wave_barrier();
+                    float a0 = 0.f, a1 = 0.f;                     // lane = channel
+#pragma unroll 4
+                    for (int r = 0; r < 32; r += 2) {
+                        a0 += ev[r] * bf2f(*(const unsigned short*)(priv + r * L::PITCH + lane_o * 2));
+                        a1 += ev[r + 1] * bf2f(*(const unsigned short*)(priv + (r + 1) * L::PITCH + lane_o * 2));
+                    }
+                    const int srow = ti.thi * 4 + wave;            // strip row inside the frame (2 image rows each)
+                    if (srow * 2 < H) {                            // strips below the frame do not exist in the record list
+                        float* dst = p.se_part + ((((int64_t)ti.b * T + ti.t) * ((H + 1) / 2) + srow) * p.tiles_w + ti.twi) * (BCO + 2);
+                        dst[2 + lane_o] = a0 + a1;
+                        if (lane_o == 0) { dst[0] = mx; dst[1] = sw; }
+                    }
                 }
             }
         }
-        __syncthreads();                                    // LDS is reused by the next segment's halo image
-        x = xe;
+        if (!has_next) break;
+        __syncthreads();                                    // every wave left its private tile: LDS becomes the halo image again
+        S = N;
     }
+    C3_PROF(4)
+    C3_PROF_END
 }
 
 // ------------------------------------------------------------------------------- host side
 namespace {
 
 struct Plan3 {
-    int bco, th, tw, tiles_h, tiles_w, nchunk, n_co_tiles;
+    int tiles_h, tiles_w, nchunk, n_co_tiles;
     int64_t M, n_tiles;
     uint64_t gtot;
     int workers;
     size_t slab_bytes;
 };
 
-inline int cus_of_current_device() {
+inline int cus_of_current_device() {      // not cached: a process may drive several devices
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
@@ -442,44 +560,61 @@ inline bool eligible3(const mv2_conv_desc& d) {
     const int es = d.dtype == MV2_BF16 ? 2 : 4;
     return d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.kt >= 1 && d.kt <= 3 &&
            d.pt == d.kt - 1 && d.check_bounds && (d.Ci * es) % 128 == 0 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi &&
-           d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) && d.act != MV2_ACT_GEGLU && d.co >= 64 && d.co_pad % 128 == 0 &&
-           d.co <= d.co_pad && d.store != MV2_STORE_NCTHW_F32 && (d.co % 4) == 0 && (d.out_c % 4) == 0;
+           d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) && (d.act == MV2_ACT_NONE || d.act == MV2_ACT_ELU) && d.co >= 64 && d.co_pad % 128 == 0 &&
+           d.co <= d.co_pad && d.store == MV2_STORE_ROWS && (d.co % (16 / es)) == 0 && (d.out_c % (16 / es)) == 0 && d.out_c >= d.co;
 }
 
 inline Plan3 plan3(const mv2_conv_desc& d) {
     Plan3 P;
     const int es = d.dtype == MV2_BF16 ? 2 : 4;
-    if (d.co <= 64) { P.bco = 64; P.th = 16; P.tw = 16; } else { P.bco = 128; P.th = 8; P.tw = 16; }
-    P.tiles_h = (d.Ho + P.th - 1) / P.th;
-    P.tiles_w = (d.Wo + P.tw - 1) / P.tw;
+    P.tiles_h = (d.Ho + TH - 1) / TH;
+    P.tiles_w = (d.Wo + TW - 1) / TW;
     P.nchunk = (d.Ci * es) / 128;
-    P.n_co_tiles = (d.co + P.bco - 1) / P.bco;
+    P.n_co_tiles = (d.co + BCO - 1) / BCO;
     P.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     P.n_tiles = (int64_t)P.n_co_tiles * d.B * d.Ti * P.tiles_h * P.tiles_w;
     const int pt = d.kt - 1, T = d.Ti;
     const int64_t cT = T <= pt ? (int64_t)T * (T + 1) / 2 : (int64_t)pt * (pt + 1) / 2 + (int64_t)(T - pt) * (pt + 1);
     P.gtot = (uint64_t)P.n_co_tiles * d.B * P.tiles_h * P.tiles_w * P.nchunk * (uint64_t)cT;
     const int cus = cus_of_current_device();
-    P.workers = (int)std::min<uint64_t>((uint64_t)cus, P.gtot);
+    P.workers = (int)std::min<uint64_t>((uint64_t)cus * 2, P.gtot);      // two workgroups per CU ...
+    // ... unless that leaves a worker fewer than 4 groups: such launches are chains of fixed latencies (prefetch, ticket,
+    // part sums), one workgroup per CU with twice the range is faster (measured at C = 512: T = 5, 3 groups per worker:
+    // 31.6 -> 28.6 us; T = 10, 6.75 groups: 47.1 -> 49.8 us)
+    if (P.gtot < (uint64_t)P.workers * 4) P.workers = (int)std::min<uint64_t>((uint64_t)cus, P.gtot);
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3_WORKERS")) { const int v = atoi(e); if (v > 0) P.workers = (int)std::min<uint64_t>((uint64_t)v, P.gtot); }
+#endif
     // two slab slots per worker (a worker's range cuts at most its first and its last tile)
-    P.slab_bytes = P.workers > 1 ? (size_t)2 * P.workers * (size_t)P.bco * (P.th * P.tw) * 4 : 0;
+    P.slab_bytes = P.workers > 1 ? (size_t)2 * P.workers * SLAB_BYTES : 0;
     return P;
 }
 
-template <typename E, int BCO, int TH, int TW>
+template <typename E, bool FUSED>
 int launch3(const ConvParams& p, int workers, hipStream_t st) {
-    typedef C3Cfg<E, BCO, TH, TW> Cfg;
-    // set unconditionally: the attribute is per device, a cached flag would be wrong for a second device of the process
-    hipError_t e = hipFuncSetAttribute((const void*)conv3_kernel<E, BCO, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLds);
+    typedef C3Lds<E, FUSED> L;
+    // set on every call: the attribute is per device, a cached flag would be wrong for a second device of the process
+    hipError_t e = hipFuncSetAttribute((const void*)conv3_kernel<E, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kLds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3_kernel<E, BCO, TH, TW>), dim3((unsigned)workers), dim3(256), Cfg::kLds, st, p);
+    hipLaunchKernelGGL((conv3_kernel<E, FUSED>), dim3((unsigned)workers), dim3(256), L::kLds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
 
 }  // namespace
 
+#ifdef MV2_EXPERIMENTS
+extern "C" int mv2_conv3_set_profile(void* device_buffer) {      // experiments library only (tools/k3_bench)
+    unsigned long long* v = (unsigned long long*)device_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv3_prof), &v, sizeof(v));
+}
+#endif
+
 extern "C" int mv2_conv3_eligible(const mv2_conv_desc* d) { return d && eligible3(*d) ? 1 : 0; }
+
+extern "C" int mv2_conv3_fusable(const mv2_conv_desc* d) {
+    return d && eligible3(*d) && d->dtype == MV2_BF16 && d->co == BCO && d->out_c == d->co ? 1 : 0;
+}
 
 extern "C" size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d) {
     if (!d || !eligible3(*d)) return 0;
@@ -492,44 +627,40 @@ extern "C" size_t mv2_conv3_counter_bytes(const mv2_conv_desc* d) {
 }
 
 extern "C" int mv2_conv3_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w) {
-    if (!d || !eligible3(*d)) return MV2_EINVAL;
-    const Plan3 P = plan3(*d);
-    if (tile_h) *tile_h = P.th;
-    if (tile_w) *tile_w = P.tw;
-    return P.tiles_h * P.tiles_w;
+    if (!d || !mv2_conv3_fusable(d)) return MV2_EINVAL;
+    if (tile_h) *tile_h = 2;
+    if (tile_w) *tile_w = TW;
+    return ((d->Ho + 1) / 2) * ((d->Wo + TW - 1) / TW);
 }
 
 extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp3, const float* bias,
-                         const float* rowscale, const void* residual, const void* wp2, const float* bias2, int act2,
+                         const void* wp2, const float* bias2, int act2,
                          const float* se_wk, float se_bk, float* se_part, void* out, void* workspace, size_t workspace_bytes,
                          uint32_t* counters, size_t counter_bytes, void* stream) {
     if (!d || !in || !wp3 || !out) return MV2_EINVAL;
     if (!eligible3(*d)) return MV2_EINVAL;
     if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     const Plan3 P = plan3(*d);
-    if (P.M >= (int64_t)0x7fffffff || P.gtot >= 0xffffffffull || P.n_tiles >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
+    if (P.M >= (int64_t)0x7fffffff || P.gtot >= 0xffffffffull || P.n_tiles >= (int64_t)0x7fffffff || P.slab_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     const size_t w_bytes = (size_t)d->nsteps * d->co_pad * 128;
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
-    if (residual && d->store != MV2_STORE_ROWS) return MV2_EINVAL;
     if (wp2) {       // fused second stage: bf16, the block owns every channel of its positions
-        if (d->dtype != MV2_BF16 || P.n_co_tiles != 1 || (d->co != 64 && d->co != 128) || d->store != MV2_STORE_ROWS || d->out_c != d->co ||
-            rowscale || residual) return MV2_EINVAL;
-        if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU && act2 != MV2_ACT_SILU) return MV2_EINVAL;
+        if (!mv2_conv3_fusable(d)) return MV2_EINVAL;
+        if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU) return MV2_EINVAL;
     } else if (bias2 || se_part) return MV2_EINVAL;
     if (se_part && !se_wk) return MV2_EINVAL;
     if (P.slab_bytes > 0 && (!workspace || workspace_bytes < P.slab_bytes)) return MV2_EWORKSPACE;
     if (P.workers > 1 && (!counters || counter_bytes < (size_t)P.n_tiles * sizeof(uint32_t))) return MV2_EWORKSPACE;
     ConvParams p{};
-    p.d = *d; p.in = in; p.wp = wp3; p.segs = nullptr; p.bias = bias; p.rowscale = rowscale; p.residual = residual;
+    p.d = *d; p.in = in; p.wp = wp3; p.segs = nullptr; p.bias = bias; p.rowscale = nullptr; p.residual = nullptr;
     p.out = out; p.ws = (float*)workspace;
     p.wp2 = wp2; p.bias2 = bias2; p.act2 = act2;
     p.se_wk = se_wk; p.se_bk = se_bk; p.se_part = se_part;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = P.M; p.n_co_tiles = P.n_co_tiles; p.n_pos_tiles = (int)(P.n_tiles / P.n_co_tiles);
     p.splitk = 1; p.tiles_h = P.tiles_h; p.tiles_w = P.tiles_w; p.nchunk = P.nchunk; p.chunks_per_split = P.nchunk;
-    p.counters = counters; p.gtot = (uint32_t)P.gtot;
+    p.counters = counters; p.gtot = (uint32_t)P.gtot; p.ws_bytes = (uint32_t)P.slab_bytes;
     hipStream_t st = (hipStream_t)stream;
-    const bool bf = d->dtype == MV2_BF16;
-    if (P.bco == 128) return bf ? launch3<BF16, 128, 8, 16>(p, P.workers, st) : launch3<F32, 128, 8, 16>(p, P.workers, st);
-    return bf ? launch3<BF16, 64, 16, 16>(p, P.workers, st) : launch3<F32, 64, 16, 16>(p, P.workers, st);
+    if (wp2) return launch3<BF16, true>(p, P.workers, st);
+    return d->dtype == MV2_BF16 ? launch3<BF16, false>(p, P.workers, st) : launch3<F32, false>(p, P.workers, st);
 }

@@ -39,6 +39,7 @@ struct ConvParams {
     // conv3.hip: stream-K ticket words (one per output tile, zero between launches) and the length of the group list
     uint32_t* counters;
     uint32_t gtot;
+    uint32_t ws_bytes;
 };
 
 #ifdef MV2_EXPERIMENTS

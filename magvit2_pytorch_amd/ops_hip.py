@@ -38,10 +38,11 @@ _SIGS = {
     'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_conv3_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
+    'mv2_conv3_fusable': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv3_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'mv2_conv3_counter_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'mv2_conv3_tiles': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    'mv2_conv3': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    'mv2_conv3': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_video_to_ndhwc': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     'mv2_rms_rowscale': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -147,6 +148,10 @@ class HipOps:
         desc = ConvDesc(**d)
         return bool(self.lib.mv2_conv3_eligible(C.byref(desc)))
 
+    def conv3_fusable(self, d: dict) -> bool:
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv3_fusable(C.byref(desc)))
+
     def conv3_sizes(self, d: dict):
         """(slab workspace bytes, ticket-counter bytes) of mv2_conv3 for this descriptor on this device."""
         desc = ConvDesc(**d)
@@ -154,7 +159,7 @@ class HipOps:
             return int(self.lib.mv2_conv3_workspace_bytes(C.byref(desc))), int(self.lib.mv2_conv3_counter_bytes(C.byref(desc)))
 
     def conv3_tiles(self, d: dict):
-        """(tiles per frame, tile_h, tile_w): the SqueezeExcite pooling records written by the fused kernel."""
+        """(strips per frame, 2, 16): the SqueezeExcite pooling records written by the fused kernel."""
         desc = ConvDesc(**d)
         th, tw = C.c_int(0), C.c_int(0)
         n = self.lib.mv2_conv3_tiles(C.byref(desc), C.byref(th), C.byref(tw))
@@ -162,14 +167,14 @@ class HipOps:
             raise Mv2Error(f'mv2_conv3_tiles failed: {n}')
         return n, th.value, tw.value
 
-    def conv3(self, d: dict, x, in_bytes, wp3, bias, out, ws, counters, rowscale=None, residual=None, wp2=None, bias2=None, act2=0,
+    def conv3(self, d: dict, x, in_bytes, wp3, bias, out, ws, counters, wp2=None, bias2=None, act2=0,
               se_wk=None, se_bk=0.0, se_part=None):
         desc = ConvDesc(**d)
         fn = self.lib.mv2_conv3
         nb = lambda t: 0 if t is None else t.numel() * t.element_size()
-        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp3), _ptr(bias), _ptr(rowscale), _ptr(residual), _ptr(wp2), _ptr(bias2), int(act2),
+        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp3), _ptr(bias), _ptr(wp2), _ptr(bias2), int(act2),
                 _ptr(se_wk), float(se_bk), _ptr(se_part), _ptr(out), _ptr(ws), nb(ws), _ptr(counters), nb(counters))
-        keep = (desc, x, wp3, bias, rowscale, residual, wp2, bias2, se_wk, se_part, out, ws, counters)
+        keep = (desc, x, wp3, bias, wp2, bias2, se_wk, se_part, out, ws, counters)
         return _mk(fn, args, 'mv2_conv3', keep, [out, se_part])
 
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):

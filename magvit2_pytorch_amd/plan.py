@@ -265,6 +265,7 @@ class Plan:
         assert ops.conv3_eligible(d), 'fragment-major weights but the descriptor is not mv2_conv3-eligible'
         out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
         ws_bytes, cnt_bytes = ops.conv3_sizes(d)
+        assert not fuse_k1 or ops.conv3_fusable(d)
         ws = self.arena.get((ws_bytes + 3) // 4, torch.float32) if ws_bytes > 0 else None
         kw, pw_part = {}, None
         if fuse_k1:
@@ -311,8 +312,8 @@ class Plan:
         pc3, pc1 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         pw_part = None
         if pc3.frag_major:
-            # mv2_conv3; bf16 at C <= 128 (a block owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
-            fuse = self.dtype == torch.bfloat16 and pc3.co in (64, 128) and pc1.co == pc3.co and pc1.kt == 1
+            # mv2_conv3; bf16 at C = 64 (a workgroup owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
+            fuse = self.dtype == torch.bfloat16 and pc3.co == 64 and pc1.co == pc3.co and pc1.kt == 1 and not os.environ.get('MV2_NO_FUSE_PW')
             y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and not os.environ.get('MV2_NO_FUSE_POOL') else None))
             if fuse:
                 y2 = y1

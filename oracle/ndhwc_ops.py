@@ -146,15 +146,18 @@ class CpuOps:
         return (d['dtype'] in (0, 1) and d['kh'] == 3 and d['kw'] == 3 and d['st'] == d['sh'] == d['sw'] == 1 and d['ph'] == d['pw'] == 1
                 and 1 <= d['kt'] <= 3 and d['pt'] == d['kt'] - 1 and d['check_bounds'] and (d['Ci'] * es) % 128 == 0
                 and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['nsteps'] == d['kt'] * 9 * ((d['Ci'] * es) // 128)
-                and d['act'] != ACT_GEGLU and d['co'] >= 64 and d['co_pad'] % 128 == 0 and d['store'] != STORE_NCTHW_F32
-                and d['co'] % 4 == 0 and d['out_c'] % 4 == 0)
+                and d['act'] in (ACT_NONE, ACT_ELU) and d['co'] >= 64 and d['co_pad'] % 128 == 0 and d['store'] == STORE_ROWS
+                and d['co'] % (16 // es) == 0 and d['out_c'] % (16 // es) == 0 and d['out_c'] >= d['co'])
+
+    def conv3_fusable(self, d):
+        return bool(self.conv3_eligible(d) and d['dtype'] == 0 and d['co'] == 64 and d['out_c'] == d['co'])
 
     def conv3_sizes(self, d):
         return 0, 0
 
     def conv3_tiles(self, d):
-        # tile menu of conv3.hip: 16x16 positions at C_out <= 64, 8x16 above
-        th, tw = (16, 16) if d['co'] <= 64 else (8, 16)
+        # SE pooling records of the fused launch: one per 2 x 16 strip of positions (include/mv2.h)
+        th, tw = 2, 16
         return (-(-d['Ho'] // th)) * (-(-d['Wo'] // tw)), th, tw
 
     @staticmethod
@@ -170,7 +173,7 @@ class CpuOps:
                 plain[:, :, :, 2 * ks + half, :] = src[:, :, ks, half, :, :]
         return plain.reshape(ns, cp, kel)
 
-    def conv3(self, d, x, in_bytes, wp3, bias, out, ws, counters, rowscale=None, residual=None, wp2=None, bias2=None, act2=0,
+    def conv3(self, d, x, in_bytes, wp3, bias, out, ws, counters, wp2=None, bias2=None, act2=0,
               se_wk=None, se_bk=0.0, se_part=None):
         """stride-1 kt x 3 x 3 causal conv (+ bias, act), optionally followed by the 1x1x1 conv (+ bias2, act2) and the per-tile
         SqueezeExcite pooling partials (include/mv2.h mv2_conv3): the intermediate is rounded to the storage dtype exactly
@@ -191,14 +194,13 @@ class CpuOps:
         co = d['co']
         dd = dict(d, seg_bytes=128)
         if wp2 is None:
-            first = self.conv(dd, x, in_bytes, wp, segs, bias, rowscale, residual, out, None)
+            first = self.conv(dd, x, in_bytes, wp, segs, bias, None, None, out, None)
 
             def step(stream):
                 first(stream)
             step.outs = [out]
             step.what = 'conv3'
             return step
-        assert rowscale is None and residual is None
         mid = torch.full((M * co,), float('nan'), dtype=x.dtype)
         first = self.conv(dd, x, in_bytes, wp, segs, bias, None, None, mid, None)
         d2 = dict(d, Ti=d['To'], Hi=d['Ho'], Wi=d['Wo'], Ci=co, kt=1, kh=1, kw=1, pt=0, ph=0, pw=0, nsteps=co * es // 128,

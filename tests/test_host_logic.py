@@ -54,7 +54,7 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     d = ops_hip.ConvDesc(**good)
     # null pointers
     assert lib.mv2_conv(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, 0, None) == EINVAL
-    assert lib.mv2_conv3(ctypes.byref(d), None, 0, None, None, None, None, None, None, 1, None, 0.0, None, None, None, 0, None, 0, None) == EINVAL
+    assert lib.mv2_conv3(ctypes.byref(d), None, 0, None, None, None, None, 1, None, 0.0, None, None, None, 0, None, 0, None) == EINVAL
     # malformed descriptors: co_pad not a multiple of 128, unknown dtype, GEGLU with odd widths
     for bad in (dict(co_pad=96), dict(dtype=7), dict(act=3, co=100, out_c=50), dict(seg_bytes=48), dict(kt=9)):
         dd = ops_hip.ConvDesc(**dict(good, **bad))
@@ -62,20 +62,21 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     # mv2_conv3 eligibility / tiling is pure host logic: stride-1 causal kt x 3 x 3 over whole 128-byte chunks, C_out >= 64
     assert lib.mv2_conv3_eligible(ctypes.byref(d)) == 1
     th, tw = ctypes.c_int(0), ctypes.c_int(0)
-    assert lib.mv2_conv3_tiles(ctypes.byref(d), ctypes.byref(th), ctypes.byref(tw)) == 1 and (th.value, tw.value) == (16, 16)
+    assert lib.mv2_conv3_fusable(ctypes.byref(d)) == 1
+    assert lib.mv2_conv3_tiles(ctypes.byref(d), ctypes.byref(th), ctypes.byref(tw)) == 8 and (th.value, tw.value) == (2, 16)
     d256 = ops_hip.ConvDesc(**dict(good, co=256, co_pad=256, out_c=256, Ci=256, nsteps=108))
     assert lib.mv2_conv3_eligible(ctypes.byref(d256)) == 1
-    assert lib.mv2_conv3_tiles(ctypes.byref(d256), ctypes.byref(th), ctypes.byref(tw)) == 2 and (th.value, tw.value) == (8, 16)
-    assert lib.mv2_conv3_counter_bytes(ctypes.byref(d256)) == 4 * 2 * 4 * 2        # one ticket word per (co tile, frame, spatial tile)
-    for bad in (dict(st=2), dict(kh=5), dict(Ci=48), dict(co=32, out_c=32), dict(pt=0), dict(store=2)):
+    assert lib.mv2_conv3_fusable(ctypes.byref(d256)) == 0 and lib.mv2_conv3_tiles(ctypes.byref(d256), None, None) == EINVAL
+    assert lib.mv2_conv3_counter_bytes(ctypes.byref(d256)) == 4 * 4 * 4 * 2        # one ticket word per (co tile, frame, spatial tile)
+    for bad in (dict(st=2), dict(kh=5), dict(Ci=48), dict(co=32, out_c=32), dict(pt=0), dict(store=2), dict(store=1), dict(act=2)):
         dd = ops_hip.ConvDesc(**dict(good, **bad))
         assert lib.mv2_conv3_eligible(ctypes.byref(dd)) == 0, bad
-        assert lib.mv2_conv3_tiles(ctypes.byref(dd), None, None) == EINVAL
-        assert lib.mv2_conv3(ctypes.byref(dd), ptr, 4096, ptr, None, None, None, None, None, 0, None, 0.0, None, ptr, None, 0, None, 0, None) == EINVAL, bad
+        assert lib.mv2_conv3_fusable(ctypes.byref(dd)) == 0 and lib.mv2_conv3_tiles(ctypes.byref(dd), None, None) == EINVAL
+        assert lib.mv2_conv3(ctypes.byref(dd), ptr, 4096, ptr, None, None, None, 0, None, 0.0, None, ptr, None, 0, None, 0, None) == EINVAL, bad
     # the fused second stage needs bf16 and a block that owns every channel (C_out in {64, 128}), no rowscale / residual
-    assert lib.mv2_conv3(ctypes.byref(d256), ptr, 4096, ptr, None, None, None, ptr, None, 1, None, 0.0, None, ptr, ptr, 1 << 30, ptr, 4096, None) == EINVAL
+    assert lib.mv2_conv3(ctypes.byref(d256), ptr, 4096, ptr, None, ptr, None, 1, None, 0.0, None, ptr, ptr, 1 << 30, ptr, 4096, None) == EINVAL
     d32 = ops_hip.ConvDesc(**dict(good, dtype=1, Ci=32, nsteps=27))
-    assert lib.mv2_conv3(ctypes.byref(d32), ptr, 4096, ptr, None, None, None, ptr, None, 1, None, 0.0, None, ptr, ptr, 1 << 30, ptr, 4096, None) == EINVAL
+    assert lib.mv2_conv3(ctypes.byref(d32), ptr, 4096, ptr, None, ptr, None, 1, None, 0.0, None, ptr, ptr, 1 << 30, ptr, 4096, None) == EINVAL
     # the other entry points: null pointers / out-of-contract sizes
     assert lib.mv2_se_pool(0, None, None, 0.0, None, 1, 1, 64, 1, None) == EINVAL
     assert lib.mv2_se_pool(0, ptr, ptr, 0.0, ptr, 1, 4, 64, 8, None) == EINVAL                 # more chunks than rows
