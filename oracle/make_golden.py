@@ -40,12 +40,14 @@ CASES = {
     # BASELINE.json configs[0] and configs[1]
     'cfg1_image128': (dict(image_size=128, init_dim=32, max_dim=512, codebook_size=512, layers=README_LAYERS), (1, 3, 128, 128), 0, 1, 2),
     'cfg2_video128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (1, 3, 17, 128, 128), 0, 1, 4),
+    # BASELINE.json configs[2], per-GPU shape: 4 clips of 17 frames
+    'cfg3_batch4x128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (4, 3, 17, 128, 128), 0, 7, 8),
     # BASELINE.json configs[3] (256x256x33f; 2 of its 4 clips: clips are independent) and configs[4] (FSQ, 65 frames).
     # These two also store the oracle's pre-sign margin so the GPU test does not have to run the CPU oracle at this size.
     'cfg4_video256x33': (dict(image_size=256, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (2, 3, 33, 256, 256), 0, 1, 16),
     'cfg5_fsq128x65': (dict(image_size=128, init_dim=64, max_dim=512, use_fsq=True, fsq_levels=[8, 5, 5, 5], layers=README_LAYERS), (2, 3, 65, 128, 128), 0, 1, 16),
 }
-WITH_MARGIN = ('cfg4_video256x33', 'cfg5_fsq128x65')
+WITH_MARGIN = ('cfg3_batch4x128x17', 'cfg4_video256x33', 'cfg5_fsq128x65')
 
 
 def sha_tensors(tensors) -> str:
@@ -97,7 +99,11 @@ def generate(name):
             ocodes = orc.tokenize(video)
         assert torch.equal(ocodes, codes)
         pre = orc.taps['prequant']
-        out['margin'] = pre.abs().amin(dim=-1).reshape(codes.shape).numpy().astype(np.float32)
+        if cfg['use_fsq']:      # distance of the pre-round activation to its nearest rounding boundary, min over the code dims
+            mg = (0.5 - (pre - pre.round()).abs()).amin(dim=-1)
+        else:                   # distance of the pre-sign activation to 0, min over the code bits
+            mg = pre.abs().amin(dim=-1)
+        out['margin'] = mg.reshape(codes.shape).numpy().astype(np.float32)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f'{name}.npz')
     np.savez_compressed(path, **out)

@@ -7,8 +7,9 @@ Tolerances (stated once, used below):
                identical wherever the oracle's pre-sign activation has margin > 1e-4 (a sign can only
                flip inside the fp32 summation-order noise band), and at most 0.5 % may differ overall.
   bf16 mode  : bf16 storage + bf16 MFMA, fp32 accumulate.  Yardstick = the reference's OWN bf16-autocast
-               drift vs its fp32 (1.6-2.2 % ids, recon mean|d| 4-7e-3, max 0.35):
-               ids mismatch <= 5 %, recon mean|d| <= 1.5e-2.
+               drift vs its fp32 (1.6-2.2 % ids, recon mean|d| 4-7e-3, max 0.35).
+               Gates per fixture (BF16_GATES): ids mismatch <= 2.2 % (the yardstick's upper end; FSQ: 0.5 %) and
+               recon mean|d| <= 1.25 x the value measured on this code (so a regression by a quarter fails).
 """
 import os
 
@@ -32,6 +33,22 @@ def hip_tokenizer(kw, sd, dtype, graph=True):
     tok.compute_dtype = dtype
     tok.use_hip_graph = graph
     return tok
+
+
+# name: (max ids mismatch, max recon mean|d| = 1.25 x measured, measured values in the comment)
+BF16_GATES = {
+    'mid_lfq': (0.022, 2.8e-3),             # measured (r02, conv3 kernel) 1.04 % / 2.24e-3
+    'cfg2_video128x17': (0.022, 5.1e-3),    # measured 0.94 % / 4.05e-3
+    'cfg3_batch4x128x17': (0.022, 5.1e-3),  # measured 0.84 % / 4.03e-3
+    'cfg4_video256x33': (0.022, 8.5e-3),    # measured 1.73 % / 6.81e-3
+    'cfg5_fsq128x65': (0.005, 1.7e-3),      # measured 0.23 % / 1.30e-3
+}
+
+
+def fsq_margin(bounded):
+    """distance of every pre-round FSQ activation to its nearest rounding boundary (k + 0.5): an id can only flip inside the
+    fp32 noise band around a boundary.  min over the code dims of a token."""
+    return (0.5 - (bounded - bounded.round()).abs()).amin(dim=-1)
 
 
 def margin_check(codes, ref_codes, prequant_ref, tau, max_frac):
@@ -74,7 +91,7 @@ def run_lockstep(cfg, sd, v, dtype):
             a, b = oh.detach().cpu(), oc
             if a.dtype in (torch.int64, torch.int32):
                 frac = (a != b).float().mean().item()
-                assert frac <= 0.02, f'step {i} {sh.what}: {frac:.3%} ids differ'
+                assert frac <= 0.01, f'step {i} {sh.what}: {frac:.3%} ids differ'
             else:
                 a, b = a.float(), b.float()
                 m = torch.isfinite(b)                              # emulation NaN-poisons never-written padding
@@ -143,18 +160,27 @@ def test_fp32_mode_vs_reference_golden(name):
     if not g.cfg['use_fsq']:
         frac = margin_check(codes, g.codes, pre, 1e-4, 0.005)
     else:
-        frac = (codes.cpu() != g.codes).float().mean().item()
-        assert frac <= 0.01
+        # FSQ: ids must match wherever every code dim is further than 4e-4 from a rounding boundary
+        # (|d bounded| <= half_l |dz| <= 4 |dz|: the LFQ margin 1e-4 carried through tanh * half_l)
+        diff = codes.cpu() != g.codes
+        frac = diff.float().mean().item()
+        safe = fsq_margin(pre).reshape(diff.shape) > 4e-4
+        assert (diff & safe).sum().item() == 0, 'FSQ ids differ although every activation is clear of its rounding boundary'
+        assert frac <= 0.005, f'{frac:.4%} ids differ'
+    print(f'[{name}] fp32: ids mismatch {frac:.4%}')
+    # the full path's reconstruction: equal to the reference's when the ids are; otherwise (a flip inside the noise band -
+    # attention makes every output depend on every token) it must still be the decoder's output for the ids it returned
     if frac == 0:
         assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
         assert torch.allclose(g.sample(recon.cpu()), g.recon_sample, atol=5e-4, rtol=0)
-    # decoder alone, from the reference's ids: no quantizer sensitivity
+    assert torch.equal(tok.decode_from_code_indices(codes), recon)
+    # decoder alone, from the reference's ids: no quantizer sensitivity, always checked
     dec = tok.decode_from_code_indices(g.codes.cuda())
     assert (dec.cpu() - orecon).abs().max().item() <= 5e-4
     assert torch.allclose(g.sample(dec.cpu()), g.recon_sample, atol=5e-4, rtol=0)
 
 
-@pytest.mark.parametrize('name', ['mid_lfq', 'cfg2_video128x17'])
+@pytest.mark.parametrize('name', ['mid_lfq', 'cfg2_video128x17', 'cfg3_batch4x128x17'])
 def test_bf16_mode_within_stated_tolerance(name):
     g = Golden(name)
     sd = g.weights()
@@ -163,8 +189,9 @@ def test_bf16_mode_within_stated_tolerance(name):
     frac = (codes.cpu() != g.codes).float().mean().item()
     err = (g.sample(recon.cpu()) - g.recon_sample).abs()
     print(f'[{name}] bf16: ids mismatch {frac:.3%}, recon mean|d| {err.mean().item():.2e} max {err.max().item():.2e}')
-    assert frac <= 0.05
-    assert err.mean().item() <= 1.5e-2
+    ids_max, mean_max = BF16_GATES[name]
+    assert frac <= ids_max, f'{frac:.3%} ids differ (gate {ids_max:.1%})'
+    assert err.mean().item() <= mean_max, f'recon mean|d| {err.mean().item():.2e} (gate {mean_max:.1e})'
     dec = tok.decode_from_code_indices(g.codes.cuda())
     derr = (g.sample(dec.cpu()) - g.recon_sample).abs()
     assert derr.mean().item() <= 1.0e-2 and derr.max().item() <= 0.25
@@ -184,14 +211,14 @@ def test_full_size_configs_vs_reference_golden(name):
     assert codes.dtype == g.codes.dtype and codes.shape == g.codes.shape
     diff = codes.cpu() != g.codes
     frac = diff.float().mean().item()
-    if not g.cfg['use_fsq']:
-        assert (diff & (g.margin > 1e-4)).sum().item() == 0, 'ids differ although the oracle margin exceeds 1e-4'
-        assert frac <= 0.005, f'{frac:.4%} ids differ'
-    else:
-        assert frac <= 0.01, f'{frac:.4%} ids differ'
+    # the fixture's margin: LFQ min |pre-sign activation| (tau 1e-4); FSQ distance to the nearest rounding boundary (tau 4e-4)
+    tau = 4e-4 if g.cfg['use_fsq'] else 1e-4
+    assert (diff & (g.margin > tau)).sum().item() == 0, f'ids differ although the oracle margin exceeds {tau}'
+    assert frac <= 0.005, f'{frac:.4%} ids differ'
     if frac == 0:
         assert torch.allclose(g.sample(recon.cpu()), g.recon_sample, atol=5e-4, rtol=0)
-    dec = tok.decode_from_code_indices(g.codes.cuda())          # decoder alone, from the reference's ids
+    assert torch.equal(tok.decode_from_code_indices(codes), recon)
+    dec = tok.decode_from_code_indices(g.codes.cuda())          # decoder alone, from the reference's ids: always checked
     assert torch.allclose(g.sample(dec.cpu()), g.recon_sample, atol=5e-4, rtol=0)
     del tok
     tok = hip_tokenizer(g.kw, sd, torch.bfloat16)
@@ -199,7 +226,8 @@ def test_full_size_configs_vs_reference_golden(name):
     bfrac = (codes.cpu() != g.codes).float().mean().item()
     err = (g.sample(recon.cpu()) - g.recon_sample).abs()
     print(f'[{name}] fp32 ids mismatch {frac:.4%}; bf16 ids mismatch {bfrac:.3%}, recon mean|d| {err.mean().item():.2e}')
-    assert bfrac <= 0.05 and err.mean().item() <= 1.5e-2
+    ids_max, mean_max = BF16_GATES[name]
+    assert bfrac <= ids_max and err.mean().item() <= mean_max
     assert torch.equal(tok.decode_from_code_indices(codes), recon)      # README round trip at full size
 
 
@@ -231,9 +259,11 @@ def test_batch_independence_and_causality():
     c_all, r_all = tok(v.cuda(), return_codes=True, return_recon=True)
     for i in range(3):
         ci, ri = tok(v[i:i + 1].cuda(), return_codes=True, return_recon=True)
-        assert (ci != c_all[i:i + 1]).float().mean().item() <= 0.01
-        if torch.equal(ci, c_all[i:i + 1]):
-            assert (ri - r_all[i:i + 1]).abs().max().item() <= 1e-4
+        # the stream-K cut points of a launch depend on the batch size, so fp32 sums may associate differently:
+        # ids may flip only inside the fp32 noise band, and the reconstruction of the SAME ids must agree to round-off
+        assert (ci != c_all[i:i + 1]).float().mean().item() <= 0.002
+        di = tok.decode_from_code_indices(c_all[i:i + 1])
+        assert (di - r_all[i:i + 1]).abs().max().item() <= 1e-4
     a = tok.encode(v[:1].cuda())
     v2 = v[:1].clone(); v2[:, :, 5:] += 1.0
     b = tok.encode(v2.cuda())
@@ -269,5 +299,5 @@ def test_larger_batch_full_size_properties():
     assert torch.isfinite(r).all()
     assert torch.equal(tok.decode_from_code_indices(c), r)
     c1, r1 = tok(v[:1], return_codes=True, return_recon=True)
-    assert (c1 != c[:1]).float().mean().item() <= 0.02
-    assert (g.sample(r[:1].cpu()) - g.recon_sample).abs().mean().item() <= 1.5e-2
+    assert (c1 != c[:1]).float().mean().item() <= 0.01
+    assert (g.sample(r[:1].cpu()) - g.recon_sample).abs().mean().item() <= BF16_GATES['cfg2_video128x17'][1]
