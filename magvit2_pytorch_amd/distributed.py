@@ -81,7 +81,16 @@ def reduce_metrics(sums: Dict[str, float], device=None) -> Dict[str, float]:
 def tokenize_sharded(tokenizer, video: torch.Tensor, gather: bool = True):
     """each rank tokenizes its shard of the global batch; optionally gathers all ids everywhere."""
     local = shard_batch(video)
-    codes = tokenizer.tokenize(local.to(tokenizer.device) if tokenizer.device.type == 'cuda' else local)
+    if local.shape[0] == 0:
+        # more ranks than clips: this rank has nothing to encode but still joins the collective (an empty shard must not
+        # build a zero-size plan while the other ranks wait in all_gather)
+        T = video.shape[2] if video.ndim == 5 else 1
+        lt = (T - 1) // tokenizer.time_downsample_factor + 1
+        tail = (lt, tokenizer.fmap_size, tokenizer.fmap_size) + ((tokenizer.cfg['num_codebooks'],) if tokenizer.cfg['num_codebooks'] > 1 else ())
+        dev = tokenizer.device if tokenizer.device.type == 'cuda' else video.device
+        codes = torch.zeros((0,) + tail, dtype=torch.int32 if tokenizer.use_fsq else torch.int64, device=dev)
+    else:
+        codes = tokenizer.tokenize(local.to(tokenizer.device) if tokenizer.device.type == 'cuda' else local)
     return gather_codes(codes, video.shape[0]) if gather else codes
 
 
@@ -89,10 +98,14 @@ def tokenize_sharded(tokenizer, video: torch.Tensor, gather: bool = True):
 def reconstruction_metrics_sharded(tokenizer, video: torch.Tensor) -> Dict[str, float]:
     """global MSE / PSNR of forward(video) over a sharded batch: local sums + one tiny all_reduce."""
     local = shard_batch(video)
-    dev_in = local.to(tokenizer.device) if tokenizer.device.type == 'cuda' else local
-    recon = tokenizer(dev_in, return_recon=True)
-    ref = dev_in.unsqueeze(2) if dev_in.ndim == 4 else dev_in
-    se = (recon.float() - ref.float()).pow(2).sum().item()
-    tot = reduce_metrics(dict(se=se, n=float(ref.numel())), device=recon.device if recon.is_cuda else None)
+    on_gpu = tokenizer.device.type == 'cuda'
+    if local.shape[0] == 0:                      # empty shard: contribute zeros, still join the all_reduce
+        se, n = 0.0, 0.0
+    else:
+        dev_in = local.to(tokenizer.device) if on_gpu else local
+        recon = tokenizer(dev_in, return_recon=True)
+        ref = dev_in.unsqueeze(2) if dev_in.ndim == 4 else dev_in
+        se, n = (recon.float() - ref.float()).pow(2).sum().item(), float(ref.numel())
+    tot = reduce_metrics(dict(se=se, n=n), device=tokenizer.device if on_gpu else None)
     mse = tot['se'] / max(tot['n'], 1.0)
     return dict(mse=mse, psnr=float('inf') if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item())

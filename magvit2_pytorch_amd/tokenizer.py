@@ -120,6 +120,7 @@ class VideoTokenizer(nn.Module):
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
             linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads)
 
+        self._validate_widths(channels, stages=S.parse_layers(self.cfg['layers'], init_dim, max_dim))
         self.channels = channels
         self.image_size = image_size
         self.use_fsq = use_fsq
@@ -145,11 +146,26 @@ class VideoTokenizer(nn.Module):
 
         self.compute_dtype: Optional[torch.dtype] = None      # None = infer (see module docstring)
         self.use_hip_graph = True
+        self.max_cached_plans = 8                 # input geometries (B, T, dtype) kept resident; least recently used is dropped
         self._ops = None
         self._packed: Dict[tuple, PackedModel] = {}
         self._plans: Dict[tuple, Plan] = {}
         self._graphs: Dict[tuple, object] = {}
         self._weights_version = 0
+
+    @staticmethod
+    def _validate_widths(channels, stages):
+        """Channel widths the kernels support: conv_in packs <= 4 input channels per pixel; rows are moved in
+        16-byte chunks (8 bf16), RMSNorm / TokenShift kernels split rows into power-of-two lane groups."""
+        if channels > 4:
+            raise NotImplementedError(f'channels={channels}: the input convolution packs at most 4 channels per pixel')
+        pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
+        for st in stages:
+            for dim in {st.dim, st.dim_out}:
+                if dim % 8 != 0:
+                    raise NotImplementedError(f'layer width {dim} ({st.kind}): widths must be multiples of 8 (16-byte bf16 chunks)')
+            if st.kind in ('attend_space', 'attend_time', 'linear_attend_space') and not pow2(st.dim):
+                raise NotImplementedError(f'{st.kind} at width {st.dim}: the RMSNorm / TokenShift kernels need a power-of-two width')
 
     # ------------------------------------------------------------------ weights
     @property
@@ -177,6 +193,8 @@ class VideoTokenizer(nn.Module):
         out = super()._apply(fn, *a, **k)
         if hasattr(self, '_packed'):
             self.refresh_weights()
+            if self._ops is not None and getattr(self._ops, 'name', '') == 'hip' and self._ops.device != self.device:
+                self._ops = None          # .to('cuda:1') / .cuda(n): rebind the launcher (and all buffers) to the new device
         return out
 
     def save(self, path, overwrite=True):
@@ -207,6 +225,9 @@ class VideoTokenizer(nn.Module):
         self.refresh_weights()
 
     def _backend(self):
+        if self._ops is not None and getattr(self._ops, 'name', '') == 'hip' and self._ops.device != self.device:
+            self._ops = None
+            self.refresh_weights()
         if self._ops is None:
             from .ops_hip import HipOps           # raises if the library / a HIP device is missing: no CPU fallback
             dev = self.device
@@ -232,7 +253,14 @@ class VideoTokenizer(nn.Module):
             self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops)
         kp = (dt, self._weights_version, B, T, want_prequant)
         if kp not in self._plans:
+            while len(self._plans) >= self.max_cached_plans:      # LRU: a plan owns an activation arena and up to 4 HIP graphs
+                old = next(iter(self._plans))
+                del self._plans[old]
+                for gk in [gk for gk in self._graphs if gk[0] == old]:
+                    del self._graphs[gk]
             self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant)
+        else:
+            self._plans[kp] = self._plans.pop(kp)                  # most recently used last
         return self._plans[kp], kp
 
     def _run(self, plan: Plan, key, which: str, step_lists):
@@ -240,25 +268,30 @@ class VideoTokenizer(nn.Module):
         second use (first use runs eagerly: it also performs one-time kernel attribute setup)."""
         ops = plan.ops
         gkey = (key, which)
-        if getattr(ops, 'name', '') != 'hip' or not self.use_hip_graph:
+        if getattr(ops, 'name', '') != 'hip':
             for steps in step_lists:
                 plan.run(steps)
             return
-        g = self._graphs.get(gkey)
-        if g is None:
-            for steps in step_lists:
-                plan.run(steps)
-            self._graphs[gkey] = 'warm'
-            return
-        if g == 'warm':
-            torch.cuda.synchronize(ops.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+        with torch.cuda.device(ops.device):      # launches, capture and replay on the backend's device, whatever is current
+            if not self.use_hip_graph:
                 for steps in step_lists:
                     plan.run(steps)
-            self._graphs[gkey] = graph
-            g = graph
-        g.replay()
+                return
+            g = self._graphs.get(gkey)
+            if g is None:
+                for steps in step_lists:
+                    plan.run(steps)
+                self._graphs[gkey] = 'warm'
+                return
+            if g == 'warm':
+                torch.cuda.synchronize(ops.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for steps in step_lists:
+                        plan.run(steps)
+                self._graphs[gkey] = graph
+                g = graph
+            g.replay()
 
     # ------------------------------------------------------------------ helpers
     def _check_video(self, video_or_images):

@@ -50,7 +50,7 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('total', [4, 3])      # 3: ragged split (2 + 1)
+@pytest.mark.parametrize('total', [4, 3, 1])      # 3: ragged split (2 + 1); 1: rank 1 holds an EMPTY shard and still joins the collectives
 def test_two_rank_sharding_matches_single_process(total):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -245,3 +245,24 @@ def test_squeeze_excite_forms_agree(monkeypatch):
     c_codes, c_recon = emulated_tokenizer(kw, sd, torch.bfloat16)(v, return_codes=True, return_recon=True)
     assert (b_codes != c_codes).float().mean().item() <= 0.02
     assert (b_recon - c_recon).abs().mean().item() < 5e-3
+
+
+def test_unsupported_widths_are_rejected_at_construction():
+    """widths the kernels cannot run must fail in the constructor with a clear message, not as an opaque
+    error code at the first forward."""
+    for bad in (dict(channels=5), dict(init_dim=12), dict(init_dim=24, layers=('attend_space',))):
+        with pytest.raises(NotImplementedError):
+            VideoTokenizer(image_size=32, codebook_size=256, **{**dict(init_dim=8, max_dim=64, layers=README_LAYERS), **bad})
+
+
+def test_plan_cache_is_bounded():
+    """one Plan (activation arena + graphs) per input geometry must not accumulate without bound."""
+    from oracle.ndhwc_ops import CpuOps
+    tok = VideoTokenizer(image_size=32, init_dim=8, max_dim=32, codebook_size=256, layers=README_LAYERS, seed=0)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.max_cached_plans = 2
+    for b in (1, 2, 3, 1):
+        tok.tokenize(torch.randn(b, 3, 5, 32, 32, generator=torch.Generator().manual_seed(b)))
+        assert len(tok._plans) <= 2
+    assert {k[2] for k in tok._plans} == {3, 1}            # least recently used (B = 2) was dropped
