@@ -14,6 +14,22 @@
 #include <cstdlib>
 #include "conv_common.h"
 
+#ifdef MV2_EXPERIMENTS
+// phase clocks per workgroup (tools/k3_bench): [0] prologue (row decode, first loads) [1] K loop [2] epilogue [7] whole kernel
+__device__ unsigned long long* g_conv_prof = nullptr;
+extern "C" int mv2_conv_set_profile(void* device_buffer) {
+    unsigned long long* v = (unsigned long long*)device_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), &v, sizeof(v));
+}
+#define CV_PROF_DECL unsigned long long pf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_ = __builtin_amdgcn_s_memtime(); const unsigned long long pt0_ = pt_;
+#define CV_PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
+#define CV_PROF_END if (g_conv_prof && threadIdx.x == 0 && blockIdx.y == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; for (int i_ = 0; i_ < 8; ++i_) g_conv_prof[(size_t)blockIdx.x * 8 + i_] = pf_[i_]; }
+#else
+#define CV_PROF_DECL
+#define CV_PROF(k)
+#define CV_PROF_END
+#endif
+
 // ------------------------------------------------------------------------------- main kernel
 template <typename E, int BCO, int BPOS, int WCO, int WPOS>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
@@ -28,6 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid & 7, r0 = tid >> 3;
     const int hi = lane >> 5, l31 = lane & 31;
+    CV_PROF_DECL
 
     // ---- block -> (co tile, pos tile); XCD-aware: blocks of one XCD walk neighbouring tiles
     int bid = blockIdx.x;
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         issue_loads(s_begin + 1, sg1, IC<1>{});
         write_lds(IC<0>{});
         __syncthreads();
+        CV_PROF(0)
         auto step = [&](int s, auto par_c) {
             constexpr int PAR = decltype(par_c)::value;
             const mv2_seg nxt = load_seg(s + 3);
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         }
         if (s < s_end) step(s, IC<0>{});
     }
+    CV_PROF(1)
 
     // ---- epilogue: acc[a][b][r] is D[co = 8*(r>>2) + 4*hi + (r&3)][pos = l31] of tile (a, b)
     const int nbase = n0 + wco * 32 * WCO;
@@ -210,6 +229,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     }
     if (stage_ok(p)) {   // LDS-staged, fully coalesced stores (the K loop ended on a barrier: LDS is free)
         staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; });
+        CV_PROF(2)
+        CV_PROF_END
         return;
     }
     if (d.act == MV2_ACT_GEGLU) {

@@ -40,7 +40,7 @@ __device__ __forceinline__ void pos_of(int pp, int& ph, int& pw) {
 
 struct TileInfo {
     int co_tile, b, t, thi, twi, v;     // v = number of valid time taps of this output frame (causal front)
-    uint32_t G0, ng;                    // linear index of the tile's first group, groups in the tile
+    uint32_t G0, ng;                    // virtual index of the tile's first unit, REAL groups in the tile
     uint32_t L;                         // linear tile id (ticket index)
 };
 
@@ -49,29 +49,35 @@ __device__ __forceinline__ uint32_t cum_taps(int t, int pt) {
     return t <= pt ? (uint32_t)(t * (t + 1) / 2) : (uint32_t)(pt * (pt + 1) / 2 + (t - pt) * (pt + 1));
 }
 
-__device__ __forceinline__ TileInfo decode_group(const ConvParams& p, uint32_t x) {
+// The work list is tile-major.  A tile of ng groups occupies ng + delta consecutive units of it: delta "virtual" units
+// for the per-tile fixed cost (cross-wave reduce, finishing the tile, epilogue) followed by its ng groups of 9 taps.
+// Equal shares of UNITS then give a worker that owns many tile starts fewer groups (measured imbalance with delta = 0:
+// slowest workgroup 1.35 x the average at C = 512).  Decodes unit x into its tile; g = position inside the tile (may
+// be < delta).
+__device__ __forceinline__ TileInfo decode_unit(const ConvParams& p, uint32_t x, uint32_t& g_virtual) {
     const mv2_conv_desc& d = p.d;
     const int pt = d.kt - 1;
+    const uint32_t delta = p.delta;
     const uint32_t u = (uint32_t)(p.tiles_h * p.tiles_w);
-    const uint32_t unit = u * (uint32_t)p.nchunk;
-    const uint32_t X1 = unit * cum_taps(d.Ti, pt);
+    auto F = [&](int t) { return u * ((uint32_t)p.nchunk * cum_taps(t, pt) + delta * (uint32_t)t); };     // units before frame t
+    const uint32_t X1 = F(d.Ti);
     TileInfo ti;
     const uint32_t cb = x / X1, r = x - cb * X1;
     ti.co_tile = (int)(cb / (uint32_t)d.B);
     ti.b = (int)(cb - (uint32_t)ti.co_tile * (uint32_t)d.B);
-    const uint32_t y = r / unit;
     int t = 0;
-    const uint32_t ramp = (uint32_t)(pt * (pt + 1) / 2);
-    if (y < ramp) { while (cum_taps(t + 1, pt) <= y) ++t; }
-    else t = pt + (int)((y - ramp) / (uint32_t)(pt + 1));
+    if (r < F(pt)) { while (F(t + 1) <= r) ++t; }
+    else t = pt + (int)((r - F(pt)) / (u * ((uint32_t)p.nchunk * (uint32_t)(pt + 1) + delta)));
     ti.t = t;
     ti.v = min(t, pt) + 1;
-    const uint32_t r2 = r - unit * cum_taps(t, pt);
+    const uint32_t r2 = r - F(t);
     ti.ng = (uint32_t)(p.nchunk * ti.v);
-    const uint32_t sp = r2 / ti.ng, g = r2 - sp * ti.ng;
+    const uint32_t vs = ti.ng + delta;
+    const uint32_t sp = r2 / vs;
+    g_virtual = r2 - sp * vs;
     ti.thi = (int)(sp / (uint32_t)p.tiles_w);
     ti.twi = (int)(sp - (uint32_t)ti.thi * (uint32_t)p.tiles_w);
-    ti.G0 = x - g;
+    ti.G0 = x - g_virtual;
     ti.L = (((uint32_t)ti.co_tile * (uint32_t)d.B + (uint32_t)ti.b) * (uint32_t)d.Ti + (uint32_t)t) * u + sp;
     return ti;
 }
@@ -114,14 +120,16 @@ struct C3Lds {
 // phase clocks (s_memtime) per workgroup: [0] prologue [1] tap loop [2] cross-wave reduce [3] partial/ticket [4] epilogue
 // [5] segments [6] groups [7] whole kernel; written to g_conv3_prof when tools/k3_bench asks for it
 __device__ unsigned long long* g_conv3_prof = nullptr;
-#define C3_PROF_DECL unsigned long long pf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_ = __builtin_amdgcn_s_memtime(); const unsigned long long pt0_ = pt_;
+#define C3_PROF_DECL unsigned long long pf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long qf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_ = __builtin_amdgcn_s_memtime(); const unsigned long long pt0_ = pt_;
+#define C3_SUB(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); qf_[k] += n_ - pt_; pf_[4] += n_ - pt_; pt_ = n_; }
 #define C3_PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
 #define C3_PROF_COUNT(k, v) pf_[k] += (v);
-#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; for (int i_ = 0; i_ < 8; ++i_) g_conv3_prof[(size_t)blockIdx.x * 8 + i_] = pf_[i_]; }
+#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; for (int i_ = 0; i_ < 8; ++i_) { g_conv3_prof[(size_t)blockIdx.x * 16 + i_] = pf_[i_]; g_conv3_prof[(size_t)blockIdx.x * 16 + 8 + i_] = qf_[i_]; } }
 #else
 #define C3_PROF_DECL
 #define C3_PROF(k)
 #define C3_PROF_COUNT(k, v)
+#define C3_SUB(k)
 #define C3_PROF_END
 #endif
 
@@ -197,9 +205,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     auto wbase_of = [&](int chunk, int it) { return (uint32_t)(it * 9 * p.nchunk + chunk) * w_step; };
     auto make_seg = [&](uint32_t x) {
         Seg S;
-        S.ti = decode_group(p, x);
-        S.x = x; S.xe = min(x1, S.ti.G0 + S.ti.ng);
-        S.gb = (int)(x - S.ti.G0); S.ge = (int)(S.xe - S.ti.G0);
+        uint32_t gv;
+        S.ti = decode_unit(p, x, gv);
+        S.x = x; S.xe = min(x1, S.ti.G0 + S.ti.ng + p.delta);
+        S.gb = (int)max(gv, p.delta) - (int)p.delta;                      // real groups [gb, ge) of the tile; ge == gb: only virtual units
+        S.ge = (int)max(S.xe - S.ti.G0, p.delta) - (int)p.delta;
         const int h0 = S.ti.thi * TH, w0 = S.ti.twi * TW;
         S.hmask = 0;
 #pragma unroll
@@ -263,7 +273,17 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     };
 
     C3_PROF_DECL
-    Seg S = make_seg(x0);
+    // first segment with real groups (a range may begin or end inside a tile's virtual units)
+    auto next_seg = [&](uint32_t x, Seg& O) {
+        while (x < x1) {
+            O = make_seg(x);
+            if (O.ge > O.gb) return true;
+            x = O.xe;
+        }
+        return false;
+    };
+    Seg S;
+    if (!next_seg(x0, S)) { C3_PROF_END return; }
     issue_first(S);
     for (;;) {
         C3_PROF(4)
@@ -354,9 +374,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         }
         // ---- the next segment's first halo image and weight taps start their flight now (the accumulators are dead, the
         // registers of the loads are free until the next tap loop): they land under this segment's ticket / epilogue
-        const bool has_next = S.xe < x1;
         Seg N = S;
-        if (has_next) { N = make_seg(S.xe); issue_first(N); }
+        const bool has_next = next_seg(S.xe, N);
+        if (has_next) issue_first(N);
         C3_PROF(2)
 
         // ---- a tile cut by a range boundary: publish the partial, take a ticket, the last arriver sums every part.
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         if (partial) {
             constexpr int WSLAB = SLAB_BYTES / 4;     // bytes per wave inside a slab
             const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
-            const uint32_t slot = 2 * bid + (S.x == x0 ? 0u : 1u);
+            const uint32_t slot = 2 * bid + (S.x == x0 ? 0u : 1u);      // S.x == x0 <=> this is the worker's first segment with real groups
             const uint32_t soff = slot * (uint32_t)SLAB_BYTES + (uint32_t)wave * WSLAB + (uint32_t)lane_o * 16u;
 #pragma unroll
             for (int a = 0; a < WCO; ++a)
@@ -380,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket
             __syncthreads();
-            const uint32_t w_first = worker_of(ti.G0, NW, G), w_last = worker_of(ti.G0 + ti.ng - 1, NW, G);
+            const uint32_t w_first = worker_of(ti.G0 + p.delta, NW, G), w_last = worker_of(ti.G0 + p.delta + ti.ng - 1, NW, G);
             const uint32_t nparts = w_last - w_first + 1;
             uint32_t* flag = (uint32_t*)(smem + L::kFlag);
             if (wave == 0 && lane_o == 0) {
@@ -450,6 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                     }
             };
             put_tile(acc_e, L::kBias, d.act == MV2_ACT_ELU);
+            C3_SUB(0)
             if constexpr (FUSED) {
                 // second GEMM out of LDS: out[co][pos] = sum_k W2[co][k] * tile[pos][k]; K = 64 = one 128-byte step
 #pragma unroll
@@ -469,7 +490,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                C3_SUB(1)
                 put_tile(acc_e, L::kConst2, p.act2 == MV2_ACT_ELU);
+                C3_SUB(2)
             }
             __builtin_amdgcn_wave_barrier();
             // whole rows out: 8 lanes per row (128 B bf16 / 16 lanes at fp32), 16 bytes per lane
@@ -487,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                     }
                 }
             }
+            C3_SUB(3)
             if constexpr (FUSED) {
                 if (p.se_part) {
                     // SqueezeExcite pooling partial of this wave's 2 x 16 strip of positions (reference SqueezeExcite.forward
@@ -526,11 +550,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                         dst[2 + lane_o] = a0 + a1;
                         if (lane_o == 0) { dst[0] = mx; dst[1] = sw; }
                     }
+                    C3_SUB(4)
                 }
             }
         }
         if (!has_next) break;
+        C3_SUB(5)
         __syncthreads();                                    // every wave left its private tile: LDS becomes the halo image again
+        C3_SUB(6)
         S = N;
     }
     C3_PROF(4)
@@ -543,7 +570,8 @@ namespace {
 struct Plan3 {
     int tiles_h, tiles_w, nchunk, n_co_tiles;
     int64_t M, n_tiles;
-    uint64_t gtot;
+    uint64_t gtot, units;      // real 9-tap groups; work-list units = groups + delta per tile
+    uint32_t delta;
     int workers;
     size_t slab_bytes;
 };
@@ -576,6 +604,12 @@ inline Plan3 plan3(const mv2_conv_desc& d) {
     const int pt = d.kt - 1, T = d.Ti;
     const int64_t cT = T <= pt ? (int64_t)T * (T + 1) / 2 : (int64_t)pt * (pt + 1) / 2 + (int64_t)(T - pt) * (pt + 1);
     P.gtot = (uint64_t)P.n_co_tiles * d.B * P.tiles_h * P.tiles_w * P.nchunk * (uint64_t)cT;
+    // per-tile fixed cost (cross-wave reduce, finish, epilogue ~ 10k clocks) in units of one 9-tap group (~ 2.4-4.8k clocks)
+    P.delta = 3;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3_DELTA")) P.delta = (uint32_t)atoi(e);
+#endif
+    P.units = P.gtot + (uint64_t)P.delta * (uint64_t)P.n_tiles;
     const int cus = cus_of_current_device();
     P.workers = (int)std::min<uint64_t>((uint64_t)cus * 2, P.gtot);      // two workgroups per CU ...
     // ... unless that leaves a worker fewer than 4 groups: such launches are chains of fixed latencies (prefetch, ticket,
@@ -641,7 +675,7 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
     if (!eligible3(*d)) return MV2_EINVAL;
     if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     const Plan3 P = plan3(*d);
-    if (P.M >= (int64_t)0x7fffffff || P.gtot >= 0xffffffffull || P.n_tiles >= (int64_t)0x7fffffff || P.slab_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
+    if (P.M >= (int64_t)0x7fffffff || P.units >= 0xffffffffull || P.n_tiles >= (int64_t)0x7fffffff || P.slab_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     const size_t w_bytes = (size_t)d->nsteps * d->co_pad * 128;
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     if (wp2) {       // fused second stage: bf16, the block owns every channel of its positions
@@ -659,7 +693,7 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = P.M; p.n_co_tiles = P.n_co_tiles; p.n_pos_tiles = (int)(P.n_tiles / P.n_co_tiles);
     p.splitk = 1; p.tiles_h = P.tiles_h; p.tiles_w = P.tiles_w; p.nchunk = P.nchunk; p.chunks_per_split = P.nchunk;
-    p.counters = counters; p.gtot = (uint32_t)P.gtot; p.ws_bytes = (uint32_t)P.slab_bytes;
+    p.counters = counters; p.gtot = (uint32_t)P.units; p.delta = P.delta; p.ws_bytes = (uint32_t)P.slab_bytes;
     hipStream_t st = (hipStream_t)stream;
     if (wp2) return launch3<BF16, true>(p, P.workers, st);
     return d->dtype == MV2_BF16 ? launch3<BF16, false>(p, P.workers, st) : launch3<F32, false>(p, P.workers, st);

@@ -38,7 +38,8 @@ struct ConvParams {
     float* se_part;
     // conv3.hip: stream-K ticket words (one per output tile, zero between launches) and the length of the group list
     uint32_t* counters;
-    uint32_t gtot;
+    uint32_t gtot;        // units of the work list (groups + delta virtual units per tile)
+    uint32_t delta;
     uint32_t ws_bytes;
 };
 

@@ -248,17 +248,18 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
         }
     }
     if (reps > 0 && p_setprof) {      // per-phase clocks of one launch (experiments library)
-        unsigned long long* dprof; const int NWK = 1024; CK(hipMalloc((void**)&dprof, NWK * 64)); CK(hipMemset(dprof, 0, NWK * 64));
+        unsigned long long* dprof; const int NWK = 1024; CK(hipMalloc((void**)&dprof, NWK * 128)); CK(hipMemset(dprof, 0, NWK * 128));
         for (int fz = 0; fz < ((do_fused && fusable) ? 2 : 1); ++fz) {
-            p_setprof(dprof);
-            run_new(c, b, fz, fz, st); CK(hipStreamSynchronize(st));
+            CK(hipMemset(dprof, 0, NWK * 128)); p_setprof(dprof);
             run_new(c, b, fz, fz, st); CK(hipStreamSynchronize(st));
             p_setprof(nullptr);
-            std::vector<unsigned long long> hp(NWK * 8); CK(hipMemcpy(hp.data(), dprof, NWK * 64, hipMemcpyDeviceToHost));
-            double sum[8] = {0}; int nw = 0; double mx7 = 0;
-            for (int w = 0; w < NWK; ++w) if (hp[w * 8 + 7]) { ++nw; for (int k = 0; k < 8; ++k) sum[k] += (double)hp[w * 8 + k]; if (hp[w * 8 + 7] > mx7) mx7 = (double)hp[w * 8 + 7]; }
+            std::vector<unsigned long long> hp(NWK * 16); CK(hipMemcpy(hp.data(), dprof, NWK * 128, hipMemcpyDeviceToHost));
+            double sum[8] = {0}, sub[8] = {0}; int nw = 0; double mx7 = 0;
+            for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) { ++nw; for (int k = 0; k < 8; ++k) { sum[k] += (double)hp[w * 16 + k]; sub[k] += (double)hp[w * 16 + 8 + k]; } if (hp[w * 16 + 7] > mx7) mx7 = (double)hp[w * 16 + 7]; }
             if (nw) printf("   prof %s (avg clocks / workgroup, %d wgs): prologue %.0f  taps %.0f (%.0f per tap)  reduce %.0f  ticket %.0f  epilogue %.0f | segments %.2f groups %.1f | kernel avg %.0f max %.0f\n",
                            fz ? "fused" : "plain", nw, sum[0] / nw, sum[1] / nw, sum[1] / (sum[6] * 9), sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw, mx7);
+            if (nw) printf("        epilogue parts per SEGMENT: put_tile %.0f  gemm2 %.0f  put_tile2 %.0f  row stores %.0f  SE %.0f  (to barrier %.0f, barrier %.0f)\n",
+                           sub[0] / sum[5], sub[1] / sum[5], sub[2] / sum[5], sub[3] / sum[5], sub[4] / sum[5], sub[5] / sum[5], sub[6] / sum[5]);
         }
         hipFree(dprof);
     }
@@ -266,6 +267,19 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
         const double gf = 2.0 * c.M * s.C * 27.0 * s.C * 1e-9;
         const float t_new = time_us([&] { run_new(c, b, false, false, st); }, reps, st);
         printf("   time new plain  : %7.1f us  (%6.0f TF/s)\n", t_new, gf / t_new * 1e3);
+        if (getenv("K3_DELTA")) {      // interleaved rounds, min and median per variant (clock drifts under sustained load)
+            const int dls[] = {0, 1, 2, 3, 4, 6};
+            std::vector<float> ts[6];
+            for (int round = 0; round < 7; ++round)
+                for (int k = 0; k < 6; ++k) {
+                    char buf[16]; snprintf(buf, sizeof buf, "%d", dls[k]); setenv("MV2_C3_DELTA", buf, 1);
+                    ts[k].push_back(time_us([&] { run_new(c, b, false, false, st); }, 5, st));
+                }
+            unsetenv("MV2_C3_DELTA");
+            printf("   delta sweep (min / median us):");
+            for (int k = 0; k < 6; ++k) { std::sort(ts[k].begin(), ts[k].end()); printf("  d%d: %.1f / %.1f", dls[k], ts[k][0], ts[k][3]); }
+            printf("\n");
+        }
         if (getenv("K3_SWEEP")) {
             printf("   workers sweep   :");
             for (int wk : {512, 448, 384, 320, 256, 192, 128}) {
@@ -287,15 +301,67 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
     return ok;
 }
 
+// generic mv2_conv (conv.hip) on a 1x1x1 convolution = plain GEMM rows x Ci -> Co: timing + phase clocks
+static void time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st) {
+    typedef int (*setprof_fn2)(void*);
+    static setprof_fn2 p_cvprof = nullptr; static bool looked = false;
+    if (!looked) { looked = true; p_cvprof = (setprof_fn2)dlsym(RTLD_DEFAULT, "mv2_conv_set_profile"); }
+    mv2_conv_desc d; memset(&d, 0, sizeof(d));
+    const int co_pad = (Co + 127) / 128 * 128, nsteps = Ci / 64;
+    d.dtype = MV2_BF16; d.B = 1; d.Ti = d.To = rows_t; d.Hi = d.Ho = rows_hw; d.Wi = d.Wo = rows_hw; d.Ci = Ci; d.co = Co; d.co_pad = co_pad;
+    d.st = d.sh = d.sw = 1; d.kt = d.kh = d.kw = 1; d.nsteps = nsteps; d.seg_bytes = 128; d.check_bounds = 0; d.act = act; d.store = MV2_STORE_ROWS;
+    d.rt = d.rh = d.rw = 1; d.out_c = act == MV2_ACT_GEGLU ? Co / 2 : Co;
+    const size_t M = (size_t)rows_t * rows_hw * rows_hw;
+    std::vector<uint16_t> hin(M * Ci), hw((size_t)nsteps * co_pad * 64);
+    for (auto& v : hin) v = f2bf(frand()); for (auto& v : hw) v = f2bf(frand() * 0.05f);
+    std::vector<mv2_seg> segs(nsteps); for (int i = 0; i < nsteps; ++i) { segs[i].elem_offset = i * 64; segs[i].sel = 1u | (1u << 8) | (1u << 16); }
+    std::vector<float> bias(co_pad, 0.01f);
+    void *din = to_dev(hin.data(), hin.size() * 2), *dw = to_dev(hw.data(), hw.size() * 2), *dsegs = to_dev(segs.data(), segs.size() * 8), *dbias = to_dev(bias.data(), bias.size() * 4);
+    void *dout, *dres; CK(hipMalloc(&dout, M * d.out_c * 2)); CK(hipMalloc(&dres, M * d.out_c * 2)); CK(hipMemset(dres, 0, M * d.out_c * 2));
+    const size_t wsb = p_conv_ws(&d); void* dws; CK(hipMalloc(&dws, wsb ? wsb : 16));
+    auto run = [&] { return p_conv(&d, din, M * Ci * 2, dw, (const mv2_seg*)dsegs, (const float*)dbias, nullptr, residual ? dres : nullptr, dout, dws, wsb, st); };
+    int rc = run(); CK(hipStreamSynchronize(st));
+    if (rc) { printf("   %s: mv2_conv rc=%d\n", name, rc); return; }
+    const float t = time_us(run, 20, st);
+    const double gf = 2.0 * M * Ci * (double)Co * 1e-9;
+    printf("== generic %-22s M=%zu Ci=%d Co=%d: %7.1f us (%5.0f TF/s)  split-K ws %.1f MB\n", name, M, Ci, Co, t, gf / t * 1e3, wsb / 1048576.0);
+    if (p_cvprof) {
+        unsigned long long* dprof; const int NB = 8192; CK(hipMalloc((void**)&dprof, NB * 64)); CK(hipMemset(dprof, 0, NB * 64));
+        p_cvprof(dprof); run(); CK(hipStreamSynchronize(st)); p_cvprof(nullptr);
+        std::vector<unsigned long long> hp(NB * 8); CK(hipMemcpy(hp.data(), dprof, NB * 64, hipMemcpyDeviceToHost));
+        double sum[8] = {0}; int nb = 0; double mx = 0;
+        for (int b = 0; b < NB; ++b) if (hp[b * 8 + 7]) { ++nb; for (int k = 0; k < 8; ++k) sum[k] += (double)hp[b * 8 + k]; mx = std::max(mx, (double)hp[b * 8 + 7]); }
+        if (nb) printf("   prof (avg clocks / block, %d blocks): prologue %.0f  K loop %.0f (%d steps)  epilogue %.0f | block avg %.0f max %.0f\n", nb, sum[0] / nb, sum[1] / nb, nsteps,
+                       sum[2] / nb, sum[7] / nb, mx);
+        hipFree(dprof);
+    }
+    hipFree(din); hipFree(dw); hipFree(dsegs); hipFree(dbias); hipFree(dout); hipFree(dres); hipFree(dws);
+}
+
 int main(int argc, char** argv) {
     std::string lib = argc > 1 ? argv[1] : "magvit2_pytorch_amd/libmv2_hip_exp.so";
-    void* h = dlopen(lib.c_str(), RTLD_NOW);
+    void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!h) { printf("dlopen %s: %s\n", lib.c_str(), dlerror()); return 2; }
     p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
     p_conv3 = (conv3_fn)dlsym(h, "mv2_conv3"); p_c3_ws = (ws_fn)dlsym(h, "mv2_conv3_workspace_bytes"); p_c3_cnt = (ws_fn)dlsym(h, "mv2_conv3_counter_bytes"); p_c3_fusable = (elig_fn)dlsym(h, "mv2_conv3_fusable");
     p_c3_tiles = (tiles_fn)dlsym(h, "mv2_conv3_tiles"); p_convpw = (convpw_fn)dlsym(h, "mv2_conv_pw");
     p_setprof = (setprof_fn)dlsym(h, "mv2_conv3_set_profile");
     if (!p_conv3 || !p_c3_ws || !p_c3_cnt || !p_c3_tiles) { printf("missing mv2_conv3 symbols\n"); return 2; }
+    if (argc > 2 && !strcmp(argv[2], "generic")) {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
+        time_pointwise("k1 C=512 T=20", 20, 16, 512, 512, MV2_ACT_ELU, false, st2);
+        time_pointwise("k1 C=512 T=5", 5, 16, 512, 512, MV2_ACT_ELU, false, st2);
+        time_pointwise("k1 C=256 T=20", 20, 32, 256, 256, MV2_ACT_ELU, false, st2);
+        time_pointwise("k1 C=128 T=20", 20, 64, 128, 128, MV2_ACT_ELU, false, st2);
+        time_pointwise("ff1 C=512 T=20 (geglu)", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
+        time_pointwise("ff2 C=512 T=20", 20, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        time_pointwise("ff1 C=256 T=20 (geglu)", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2);
+        time_pointwise("ff2 C=256 T=20", 20, 32, 704, 256, MV2_ACT_NONE, true, st2);
+        time_pointwise("qkv C=512 T=20", 20, 16, 512, 768, MV2_ACT_NONE, false, st2);
+        time_pointwise("out C=512 T=20", 20, 16, 256, 512, MV2_ACT_NONE, true, st2);
+        return 0;
+    }
     const bool quick = argc > 2 && (!strcmp(argv[2], "quick") || !strcmp(argv[2], "levels"));
     const bool levels_only = argc > 2 && !strcmp(argv[2], "levels");
     hipStream_t st; CK(hipStreamCreate(&st));
