@@ -453,12 +453,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             const int64_t frame_row0 = ((int64_t)ti.b * T + ti.t) * H;
             const int n0 = ti.co_tile * BCO;
             auto put_tile = [&](f32x16 (&v16)[WCO], int bias_off, bool elu) {     // bias_off: LDS offset of 64 fp32 bias values
+                f32x4 bvs[WCO * 4];                       // all eight bias reads first: one LDS latency instead of eight in a chain
+#pragma unroll
+                for (int q = 0; q < WCO * 4; ++q) bvs[q] = *(const f32x4*)(smem + bias_off + ((q >> 2) * 32 + 8 * (q & 3) + 4 * hi_o) * 4);
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int col = a * 32 + 8 * g + 4 * hi_o;
-                        const f32x4 bv = *(const f32x4*)(smem + bias_off + col * 4);
+                        const f32x4 bv = bvs[a * 4 + g];
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {

@@ -136,8 +136,12 @@ __device__ __forceinline__ void epi_geglu4(const ConvParams& p, int64_t m, int n
 template <typename E, int BCO, int BPOS>
 struct StageCfg {
     static constexpr int kPitch = BCO * E::kBytes + 16;            // bytes per staged row (pad: bank spread)
-    static constexpr int kTile = BPOS * kPitch;
-    static constexpr int kBytes = kTile + BPOS * 8;                // + destination-row table (int64 per staged row)
+    static constexpr int kPitchWide = BCO * 4 + 16;                // ... when the tile is staged in fp32 (residual add before the one rounding)
+    static constexpr int kTile = BPOS * kPitchWide;
+    static constexpr int kRowTab = kTile;                          // destination-row table (int64 per staged row)
+    static constexpr int kRowScale = kRowTab + BPOS * 8;           // per-row scale (fp32 per staged row)
+    static constexpr int kBias = kRowScale + BPOS * 4;             // bias of the block's BCO columns (fp32)
+    static constexpr int kBytes = kBias + BCO * 4;
 };
 
 template <typename E> __device__ __forceinline__ void lds_put4(char* dst, const float* v);
@@ -163,43 +167,54 @@ template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typena
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
                                                 int wpos, int tid, RowFn row_of, bool owner = true) {
     const mv2_conv_desc& d = p.d;
-    constexpr int PITCH = StageCfg<E, BCO, BPOS>::kPitch;
+    typedef StageCfg<E, BCO, BPOS> SC;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const bool geglu = d.act == MV2_ACT_GEGLU;
-    // destination row of every staged row (-1: outside the tensor), decoded once per row here so that phase 2
-    // has no division left (the depth-to-space store used to decode b,t,h,w per 16-byte chunk)
-    int64_t* rowtab = (int64_t*)(lds + StageCfg<E, BCO, BPOS>::kTile);
+    // with a residual the tile is staged in fp32: out = round(act(..) + residual), ONE rounding (staging in bf16 and adding
+    // afterwards rounds twice: measured +39 % reconstruction error on configs[1])
+    const bool wide = p.residual != nullptr && E::kBytes == 2;
+    const int PITCH = wide ? SC::kPitchWide : SC::kPitch;
+    int64_t* rowtab = (int64_t*)(lds + SC::kRowTab);
+    float* rs_lds = (float*)(lds + SC::kRowScale);
+    float* bias_lds = (float*)(lds + SC::kBias);
+    // ---- phase 0: everything the per-value math needs from global memory goes to LDS with ONE round of loads (a bias /
+    // rowscale / residual load per value made phase 1 a chain of dependent memory latencies: 7-24k clocks per block measured):
+    // destination row of every staged row (-1: outside the tensor; decoded once per row so that phase 2 has no division),
+    // its rowscale, and the bias of the block's columns.  The residual is added in phase 2, in whole 16-byte chunks.
+    for (int lp = tid; lp < BPOS; lp += NT) {
+        const int64_t m = row_of(lp);
+        const bool valid = m < p.M;
+        int64_t dr = -1;
+        if (valid) {
+            dr = m;
+            if (d.store == MV2_STORE_SHUFFLE) {
+                int b_, t_, h_, w_; decode_pos<E>(d, m, b_, t_, h_, w_);
+                dr = (((int64_t)b_ * (d.To * d.rt) + t_ * d.rt) * (d.Ho * d.rh) + h_ * d.rh) * (int64_t)(d.Wo * d.rw) + w_ * d.rw;
+            }
+        }
+        rowtab[lp] = dr;
+        rs_lds[lp] = (valid && p.rowscale) ? p.rowscale[m] : 1.f;
+    }
+    for (int q = tid; q < BCO; q += NT) bias_lds[q] = (p.bias && n0 + q < d.co_pad) ? p.bias[n0 + q] : 0.f;
+    __syncthreads();
     // ---- phase 1: finish values per lane, write the tile
 #pragma unroll
     for (int b = 0; b < WPOS; ++b) {
         if (!owner) break;
         const int lp = wpos * 32 * WPOS + b * 32 + l31;
-        const int64_t m = row_of(lp);
-        const bool valid = m < p.M;
-        if (wco == 0 && hi == 0) {
-            int64_t dr = -1;
-            if (valid) {
-                dr = m;
-                if (d.store == MV2_STORE_SHUFFLE) {
-                    int b_, t_, h_, w_; decode_pos<E>(d, m, b_, t_, h_, w_);
-                    dr = (((int64_t)b_ * (d.To * d.rt) + t_ * d.rt) * (d.Ho * d.rh) + h_ * d.rh) * (int64_t)(d.Wo * d.rw) + w_ * d.rw;
-                }
-            }
-            rowtab[lp] = dr;
-        }
-        const float rs = (valid && p.rowscale) ? p.rowscale[m] : 1.f;
+        const float rs = rs_lds[lp];
         char* rowp = lds + lp * PITCH;
         if (geglu) {
             if constexpr (WCO == 2) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int off = 8 * g + 4 * hi;
-                    const int nx = n0 + wco * 64 + off;          // packed value column; gate = +32
+                    const int cx = wco * 64 + off;               // block-local packed value column; gate = +32
+                    const f32x4 bx = *(const f32x4*)(bias_lds + cx), bg = *(const f32x4*)(bias_lds + cx + 32);
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float xv = acc[0][b][4 * g + j] * rs, gv = acc[1][b][4 * g + j] * rs;
-                        if (p.bias) { xv += p.bias[nx + j]; gv += p.bias[nx + 32 + j]; }
+                        const float xv = acc[0][b][4 * g + j] * rs + bx[j], gv = acc[1][b][4 * g + j] * rs + bg[j];
                         o[j] = Act<E>::gelu(gv) * xv;
                     }
                     lds_put4<E>(rowp + (wco * 32 + off) * E::kBytes, o);
@@ -211,29 +226,24 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int col = wco * 32 * WCO + a * 32 + 8 * g + 4 * hi;
-                    const int n = n0 + col;
+                    const f32x4 bv = *(const f32x4*)(bias_lds + col);
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float x = acc[a][b][4 * g + j] * rs;
-                        if (p.bias) x += p.bias[n + j];
+                        float x = acc[a][b][4 * g + j] * rs + bv[j];
                         if (d.act == MV2_ACT_ELU) x = Act<E>::elu(x);
                         else if (d.act == MV2_ACT_SILU) x = Act<E>::silu(x);
                         v[j] = x;
                     }
-                    if (p.residual && valid && n < d.co) {
-                        float r[4]; ld4<E>(p.residual, m * d.out_c + n, r);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += r[j];
-                    }
-                    lds_put4<E>(rowp + col * E::kBytes, v);
+                    if (wide) lds_put4<F32>(rowp + col * 4, v);
+                    else lds_put4<E>(rowp + col * E::kBytes, v);
                 }
         }
     }
     __syncthreads();
-    // ---- phase 2: coalesced 16-byte stores of whole rows.  The chunk count per row is a power of two that
-    // divides the thread count, so a thread keeps ONE channel chunk and walks rows: everything that depends on
-    // the channel (incl. the depth-to-space sub-position) is computed once, outside the loop.
+    // ---- phase 2: coalesced 16-byte stores of whole rows (+ the residual, read the same way).  The chunk count per row is a
+    // power of two that divides the thread count, so a thread keeps ONE channel chunk and walks rows: everything that depends
+    // on the channel (incl. the depth-to-space sub-position) is computed once, outside the loop.
     constexpr int CPR_FULL = BCO * E::kBytes / 16;                 // 16-byte chunks per staged row (power of two)
     static_assert((CPR_FULL & (CPR_FULL - 1)) == 0 && NT % CPR_FULL == 0, "chunk-per-thread mapping");
     const int cpr = geglu ? CPR_FULL / 2 : CPR_FULL;
@@ -252,11 +262,33 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
         coloff = (((int64_t)qt * (d.Ho * d.rh) + qh) * (int64_t)(d.Wo * d.rw) + qw) * cq + c;
         rowmul = cq;
     }
+    const bool res = p.residual != nullptr;                       // MV2_STORE_ROWS only (checked by the host)
     for (int lp = lp0; lp < BPOS; lp += lstep) {
         const int64_t dr = rowtab[lp];
         if (dr < 0) continue;
-        const i32x4 val = *(const i32x4*)(lds + lp * PITCH + ch * 16);
-        *(i32x4*)((char*)p.out + (dr * rowmul + coloff) * E::kBytes) = val;
+        const int64_t off = (dr * rowmul + coloff) * E::kBytes;
+        i32x4 val;
+        if (res) {
+            const i32x4 rv = *(const i32x4*)((const char*)p.residual + off);
+            float a_[E::kVec], r_[E::kVec];
+            bool got = false;
+            if constexpr (E::kVec == 8) {
+                if (wide) {           // 8 fp32 values = two 16-byte chunks of the wide tile
+                    const f32x4 lo = *(const f32x4*)(lds + lp * PITCH + ch * 32), hi4 = *(const f32x4*)(lds + lp * PITCH + ch * 32 + 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a_[j] = lo[j]; a_[4 + j] = hi4[j]; }
+                    got = true;
+                }
+            }
+            if (!got) Chunk<E>::unpack(*(const i32x4*)(lds + lp * PITCH + ch * 16), a_);
+            Chunk<E>::unpack(rv, r_);
+#pragma unroll
+            for (int j = 0; j < E::kVec; ++j) a_[j] += r_[j];
+            val = Chunk<E>::pack(a_);
+        } else {
+            val = *(const i32x4*)(lds + lp * PITCH + ch * 16);
+        }
+        *(i32x4*)((char*)p.out + off) = val;
     }
 }
 
