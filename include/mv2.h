@@ -238,6 +238,25 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
 int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
             int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+/* Training-mode LFQ (third-party LFQ.forward with self.training, reference call site M:1705, loss weights M:1067-1072, recon loss
+ * M:1722).  mv2_lfq_train = mv2_lfq with the straight-through forward value z + (q - z) (prequant is mandatory: it feeds
+ * the statistics).  mv2_lfq_stats: per codebook the token-SUMMED softmax probabilities over all K = 2^cb_dim codes
+ * (prob = softmax_j(2 * inv_temperature * z . c_j)), the sum over tokens and codebooks of the per-token entropies (log clamped at
+ * 1e-5) and the sum of squared commitment errors:  sums[num_codebooks * K + 2].  Ranks all_reduce(SUM) `sums` (RCCL) before
+ * mv2_lfq_losses, which turns them into losses[4] = {per-sample entropy, batch entropy, commitment, aux} with
+ * aux = (H_sample - gamma * H_batch) * w_entropy + commitment * w_commit, n_tokens = global token count.  cb_dim <= 12.
+ * mv2_sq_diff_sum: sum((a - b)^2) over n fp32 elements (F.mse_loss numerator, M:1722); 16-byte aligned pointers.
+ * All reductions have a fixed order: results are bitwise reproducible. */
+int mv2_lfq_train(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
+                  const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
+                  int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+size_t mv2_lfq_stats_workspace_bytes(int64_t rows, int cb_dim, int num_codebooks);
+int mv2_lfq_stats(const float* prequant, int64_t rows, int cb_dim, int num_codebooks, float inv_temperature, float scale,
+                  float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int mv2_lfq_losses(const float* sums, double n_tokens, int cb_dim, int num_codebooks, float diversity_gamma,
+                   float entropy_loss_weight, float commitment_loss_weight, float* losses, void* stream);
+size_t mv2_sq_diff_workspace_bytes(int64_t n);
+int mv2_sq_diff_sum(const float* a, const float* b, int64_t n, float* sum, void* workspace, size_t workspace_bytes, void* stream);
 int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out_t, const float* b_out, void* out,
                   int64_t rows, int C, int cb_dim, int num_codebooks, float scale, void* stream);
 int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,

@@ -1,6 +1,7 @@
 // LFQ / FSQ quantizers: one wavefront per token, per-token reductions by wave shuffles.
 // Restates the eval arithmetic of vector_quantize_pytorch.LFQ / FSQ (see oracle/thirdparty.py for
 // the algorithm statement; reference call sites magvit2_pytorch.py:1574, 1593, 1700, 1705).
+#include <algorithm>
 #include "common.h"
 
 #define CB_MAX 32
@@ -10,6 +11,7 @@ struct QuantParams {
     void* quantized; void* ids; float* prequant;
     int64_t rows; int C, cb_dim, ncb;
     float clamp, scale;
+    int ste;                    // LFQ training mode: the forward value is the straight-through form z + (q - z)
     // FSQ constants (per codebook dim, length cb_dim)
     const float* shift; const float* half_l; const float* offset; const float* half_w; const int32_t* basis;
 };
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(256) void lfq_kernel(const QuantParams p) {
         float z = q.z[lane];
         if (p.clamp > 0.f) z = tanhf(z / p.clamp) * p.clamp;
         q.z[lane] = z;
-        q.code[lane] = z > 0.f ? p.scale : -p.scale;
+        const float sgn = z > 0.f ? p.scale : -p.scale;
+        q.code[lane] = p.ste ? z + (sgn - z) : sgn;     // training: x + (quantized - x).detach(), the same two fp32 roundings
         if (p.prequant) p.prequant[row * cbt + lane] = z;
     }
     __builtin_amdgcn_wave_barrier();
@@ -171,12 +174,10 @@ static int check_q(int dtype, int64_t rows, int C, int cb_dim, int ncb) {
     return MV2_OK;
 }
 
-extern "C" int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
-                       void* quantized, int64_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
-                       float clamp, float scale, void* stream) {
-    if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids) return MV2_EINVAL;
-    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
-    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, clamp, scale,
+static int launch_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out, void* quantized,
+                      int64_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks, float clamp, float scale, int ste,
+                      void* stream) {
+    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, clamp, scale, ste,
                   nullptr, nullptr, nullptr, nullptr, nullptr};
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (dtype == MV2_BF16) hipLaunchKernelGGL((lfq_kernel<BF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -185,13 +186,29 @@ extern "C" int mv2_lfq(int dtype, const void* x, const float* w_in, const float*
     return MV2_OK;
 }
 
+extern "C" int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                       void* quantized, int64_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
+                       float clamp, float scale, void* stream) {
+    if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    return launch_lfq(dtype, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, clamp, scale, 0, stream);
+}
+
+extern "C" int mv2_lfq_train(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                             void* quantized, int64_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
+                             float clamp, float scale, void* stream) {
+    if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids || !prequant) return MV2_EINVAL;
+    int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
+    return launch_lfq(dtype, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, clamp, scale, 1, stream);
+}
+
 extern "C" int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
                        const float* shift, const float* half_l, const float* offset, const float* half_w, const int32_t* basis,
                        void* quantized, int32_t* ids, float* prequant, int64_t rows, int C, int cb_dim, int num_codebooks,
                        void* stream) {
     if (!x || !w_in || !b_in || !w_out || !b_out || !quantized || !ids || !shift || !half_l || !offset || !half_w || !basis) return MV2_EINVAL;
     int rc = check_q(dtype, rows, C, cb_dim, num_codebooks); if (rc) return rc;
-    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, 0.f, 1.f,
+    QuantParams p{x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, C, cb_dim, num_codebooks, 0.f, 1.f, 0,
                   shift, half_l, offset, half_w, basis};
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (dtype == MV2_BF16) hipLaunchKernelGGL((fsq_kernel<BF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -221,6 +238,175 @@ extern "C" int mv2_fsq_codes(int dtype, const int32_t* ids, const float* w_out, 
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (dtype == MV2_BF16) hipLaunchKernelGGL((codes_kernel<BF16, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((codes_kernel<F32, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+
+// ------------------------------------------------------------------------------- training-mode LFQ statistics and losses
+// Third-party LFQ.forward, training branch (reconstruction, see oracle/thirdparty.py; reference call site magvit2_pytorch.py:1705,
+// weights :1067-1072): per token and codebook  prob = softmax_j(2 * inv_temperature * z . c_j)  over all K = 2^d sign patterns c_j,
+//   per-sample entropy  H(prob) with the log clamped at 1e-5, averaged over tokens and codebooks;
+//   batch entropy       H(mean over tokens of prob), averaged over codebooks (the mean is all-reduced across ranks);
+//   commitment          mean((z - sign(z) * scale)^2);
+//   aux = (H_sample - gamma * H_batch) * w_entropy + commitment * w_commit.
+// Determinism: every reduction has a fixed order (wave shuffles, then waves in order, then workgroups in order).
+#define LFQ_KMAX_LOG2 12
+#define LFQ_CPT 16                        // codes per thread at K = 4096
+
+struct LfqStatsParams { const float* z; int64_t rows; int cb_dim, ncb; float inv_temp, scale; float* part; int64_t tok_per_block; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {      // fixed order; red: 8 floats of LDS; ends with a barrier
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void lfq_stats_kernel(const LfqStatsParams p) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int d = p.cb_dim, K = 1 << d, cbt = d * p.ncb;
+    const int64_t t0 = (int64_t)blockIdx.x * p.tok_per_block, t1 = min(p.rows, t0 + p.tok_per_block);
+    float* out = p.part + (size_t)blockIdx.x * ((size_t)p.ncb * K + 2);
+    float ent_sum = 0.f, commit_sum = 0.f;
+    for (int c = 0; c < p.ncb; ++c) {
+        float accp[LFQ_CPT];
+#pragma unroll
+        for (int u = 0; u < LFQ_CPT; ++u) accp[u] = 0.f;
+        for (int64_t tok = t0; tok < t1; ++tok) {
+            const float* zt = p.z + tok * cbt + c * d;
+            float zz[LFQ_KMAX_LOG2];
+            float mx = 0.f, cm = 0.f;
+#pragma unroll
+            for (int i = 0; i < LFQ_KMAX_LOG2; ++i) {
+                zz[i] = i < d ? zt[i] : 0.f;
+                mx += fabsf(zz[i]);
+                const float q = zz[i] > 0.f ? p.scale : -p.scale;
+                if (i < d) cm += (zz[i] - q) * (zz[i] - q);
+            }
+            const float k2 = 2.f * p.inv_temp * p.scale;
+            mx *= k2;                                                      // logit of the matching code = the maximum
+            float e[LFQ_CPT], s_local = 0.f;
+#pragma unroll
+            for (int u = 0; u < LFQ_CPT; ++u) {
+                const int j = tid + 256 * u;
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < LFQ_KMAX_LOG2; ++i) dot += (i < d) ? (((j >> (d - 1 - i)) & 1) ? zz[i] : -zz[i]) : 0.f;     // MSB first
+                e[u] = j < K ? expf(k2 * dot - mx) : 0.f;
+                s_local += e[u];
+            }
+            const float S = block_sum_256(s_local, red);
+            float h_local = 0.f;
+#pragma unroll
+            for (int u = 0; u < LFQ_CPT; ++u) {
+                const float pr = e[u] / S;
+                accp[u] += pr;
+                h_local += -pr * logf(fmaxf(pr, 1e-5f));
+            }
+            const float H = block_sum_256(h_local, red);
+            ent_sum += H;
+            commit_sum += cm;
+        }
+#pragma unroll
+        for (int u = 0; u < LFQ_CPT; ++u) { const int j = tid + 256 * u; if (j < K) out[(size_t)c * K + j] = accp[u]; }
+    }
+    if (tid == 0) { out[(size_t)p.ncb * K] = ent_sum; out[(size_t)p.ncb * K + 1] = commit_sum; }
+}
+
+// out[col] = sum over blocks (in order) of part[blk][col]
+__global__ __launch_bounds__(256) void sum_blocks_kernel(const float* part, int nblk, int64_t ncols, float* out) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * ncols + col];
+    out[col] = s;
+}
+
+__global__ __launch_bounds__(256) void lfq_loss_kernel(const float* sums, double n_tokens, int cb_dim, int ncb, float gamma, float w_ent,
+                                                       float w_commit, float* losses) {
+    __shared__ float red[8];
+    const int K = 1 << cb_dim;
+    const float inv_n = (float)(1.0 / n_tokens);
+    float hb = 0.f;
+    for (int c = 0; c < ncb; ++c) {
+        float h_local = 0.f;
+        for (int j = threadIdx.x; j < K; j += 256) { const float a = sums[(size_t)c * K + j] * inv_n; h_local += -a * logf(fmaxf(a, 1e-5f)); }
+        hb += block_sum_256(h_local, red);
+    }
+    if (threadIdx.x == 0) {
+        const float per_sample = sums[(size_t)ncb * K] * inv_n / (float)ncb;
+        const float batch = hb / (float)ncb;
+        const float commit = w_commit > 0.f ? sums[(size_t)ncb * K + 1] * inv_n / (float)(ncb * cb_dim) : 0.f;
+        losses[0] = per_sample; losses[1] = batch; losses[2] = commit;
+        losses[3] = (per_sample - gamma * batch) * w_ent + commit * w_commit;
+    }
+}
+
+static int lfq_stats_blocks(int64_t rows) { return (int)std::min<int64_t>(rows, 512); }
+
+extern "C" size_t mv2_lfq_stats_workspace_bytes(int64_t rows, int cb_dim, int num_codebooks) {
+    if (rows <= 0 || cb_dim <= 0 || cb_dim > LFQ_KMAX_LOG2 || num_codebooks <= 0) return 0;
+    return (size_t)lfq_stats_blocks(rows) * ((size_t)num_codebooks * ((size_t)1 << cb_dim) + 2) * sizeof(float);
+}
+
+extern "C" int mv2_lfq_stats(const float* prequant, int64_t rows, int cb_dim, int num_codebooks, float inv_temperature, float scale,
+                             float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!prequant || !sums || rows <= 0 || cb_dim <= 0 || cb_dim > LFQ_KMAX_LOG2 || num_codebooks <= 0 || cb_dim * num_codebooks > CB_MAX) return MV2_EINVAL;
+    if (!workspace || workspace_bytes < mv2_lfq_stats_workspace_bytes(rows, cb_dim, num_codebooks)) return MV2_EWORKSPACE;
+    const int nblk = lfq_stats_blocks(rows);
+    const int64_t ncols = (int64_t)num_codebooks * ((int64_t)1 << cb_dim) + 2;
+    LfqStatsParams p{prequant, rows, cb_dim, num_codebooks, inv_temperature, scale, (float*)workspace, (rows + nblk - 1) / nblk};
+    hipLaunchKernelGGL(lfq_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    MV2_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, ncols, sums);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_lfq_losses(const float* sums, double n_tokens, int cb_dim, int num_codebooks, float diversity_gamma, float entropy_loss_weight,
+                              float commitment_loss_weight, float* losses, void* stream) {
+    if (!sums || !losses || !(n_tokens > 0) || cb_dim <= 0 || cb_dim > LFQ_KMAX_LOG2 || num_codebooks <= 0) return MV2_EINVAL;
+    hipLaunchKernelGGL(lfq_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, n_tokens, cb_dim, num_codebooks, diversity_gamma,
+                       entropy_loss_weight, commitment_loss_weight, losses);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// ------------------------------------------------------------------------------- sum of squared differences (F.mse_loss, M:1722)
+__global__ __launch_bounds__(256) void sq_diff_kernel(const float* a, const float* b, int64_t n, int64_t per_block, float* part) {
+    __shared__ float red[8];
+    const int64_t i0 = (int64_t)blockIdx.x * per_block, i1 = min(n, i0 + per_block);
+    float s = 0.f;
+    for (int64_t i = i0 + threadIdx.x * 4; i < i1; i += 256 * 4) {
+        if (i + 4 <= i1) {
+            const f32x4 x = *(const f32x4*)(a + i), y = *(const f32x4*)(b + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dlt = x[j] - y[j]; s += dlt * dlt; }
+        } else {
+            for (int64_t k = i; k < i1; ++k) { const float dlt = a[k] - b[k]; s += dlt * dlt; }
+        }
+    }
+    const float t = block_sum_256(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+static int sq_blocks(int64_t n) { return (int)std::min<int64_t>((n + 4095) / 4096, 1024); }
+
+extern "C" size_t mv2_sq_diff_workspace_bytes(int64_t n) { return n > 0 ? (size_t)sq_blocks(n) * sizeof(float) : 0; }
+
+extern "C" int mv2_sq_diff_sum(const float* a, const float* b, int64_t n, float* sum, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a || !b || !sum || n <= 0 || (((uintptr_t)a | (uintptr_t)b) & 15)) return MV2_EINVAL;
+    if (!workspace || workspace_bytes < mv2_sq_diff_workspace_bytes(n)) return MV2_EWORKSPACE;
+    const int nblk = sq_blocks(n);
+    int64_t per_block = (n + nblk - 1) / nblk;
+    per_block = (per_block + 3) / 4 * 4;                                  // 16-byte aligned chunk starts
+    hipLaunchKernelGGL(sq_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n, per_block, (float*)workspace);
+    MV2_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, (int64_t)1, sum);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }

@@ -55,6 +55,12 @@ _SIGS = {
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_lfq_train': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_lfq_stats_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    'mv2_lfq_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_lfq_losses': (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'mv2_sq_diff_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'mv2_sq_diff_sum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_lfq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'mv2_fsq': (C.c_int, [C.c_int] + [C.c_void_p] * 13 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_fsq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -237,6 +243,35 @@ class HipOps:
                 rows, Cc, cb_dim, ncb, float(clamp), float(scale))
         keep = (x, w_in, b_in, w_out, b_out, quantized, ids, prequant)
         return _mk(fn, args, 'mv2_lfq', keep, [quantized, ids, prequant])
+
+    def lfq_train(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
+        fn = self.lib.mv2_lfq_train
+        args = (dt, _ptr(x), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out), _ptr(quantized), _ptr(ids), _ptr(prequant),
+                rows, Cc, cb_dim, ncb, float(clamp), float(scale))
+        keep = (x, w_in, b_in, w_out, b_out, quantized, ids, prequant)
+        return _mk(fn, args, 'mv2_lfq_train', keep, [quantized, ids, prequant])
+
+    def lfq_stats_workspace_bytes(self, rows, cb_dim, ncb) -> int:
+        return int(self.lib.mv2_lfq_stats_workspace_bytes(rows, cb_dim, ncb))
+
+    def lfq_stats(self, prequant, rows, cb_dim, ncb, inv_temperature, scale, sums, ws):
+        fn = self.lib.mv2_lfq_stats
+        args = (_ptr(prequant), rows, cb_dim, ncb, float(inv_temperature), float(scale), _ptr(sums), _ptr(ws),
+                ws.numel() * ws.element_size())
+        return _mk(fn, args, 'mv2_lfq_stats', (prequant, sums, ws), [sums])
+
+    def lfq_losses(self, sums, n_tokens, cb_dim, ncb, gamma, w_entropy, w_commit, losses):
+        fn = self.lib.mv2_lfq_losses
+        args = (_ptr(sums), float(n_tokens), cb_dim, ncb, float(gamma), float(w_entropy), float(w_commit), _ptr(losses))
+        return _mk(fn, args, 'mv2_lfq_losses', (sums, losses), [losses])
+
+    def sq_diff_workspace_bytes(self, n) -> int:
+        return int(self.lib.mv2_sq_diff_workspace_bytes(n))
+
+    def sq_diff_sum(self, a, b, n, out, ws):
+        fn = self.lib.mv2_sq_diff_sum
+        args = (_ptr(a), _ptr(b), n, _ptr(out), _ptr(ws), ws.numel() * ws.element_size())
+        return _mk(fn, args, 'mv2_sq_diff_sum', (a, b, out, ws), [out])
 
     def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):
         fn, args = self.lib.mv2_lfq_codes, (dt, _ptr(ids), _ptr(w_out), _ptr(b_out), _ptr(out), rows, Cc, cb_dim, ncb, float(scale))

@@ -174,13 +174,15 @@ def _se_two_launch(Pn, C, hidden, dtype) -> bool:
 
 
 class Plan:
-    def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False):
+    def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False, train: bool = False):
         self.pm, self.ops, self.cfg = pm, pm.ops, pm.cfg
         self.dtype, self.dt = pm.dtype, pm.dt
         self.B, self.T, self.H, self.W = B, T, H, W
         self.arena = _Arena(self.ops)
         self.tdf = 2 ** sum(s.kind == 'compress_time' for s in pm.stages)
         self.time_padding = self.tdf - 1
+        self.train = train and not pm.use_fsq        # training-mode LFQ: straight-through forward value + entropy / commitment aux loss
+        want_prequant = want_prequant or self.train
         self.want_prequant = want_prequant
         self.step_names: List[str] = []
         self.step_flops: Dict[int, float] = {}      # id(step) -> algorithmic FLOPs (conv launches)
@@ -203,9 +205,26 @@ class Plan:
             self.q_steps.append(ops.fsq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, self.ids,
                                         self.prequant, x.rows, x.C, pm.cb_dim, pm.ncb))
         else:
-            self.q_steps.append(ops.lfq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, q.t, self.ids, self.prequant,
-                                        x.rows, x.C, pm.cb_dim, pm.ncb, self.cfg['lfq_soft_clamp_input_value'] or 0., 1.))
+            fwd = ops.lfq_train if self.train else ops.lfq
+            self.q_steps.append(fwd(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, q.t, self.ids, self.prequant,
+                                    x.rows, x.C, pm.cb_dim, pm.ncb, self.cfg['lfq_soft_clamp_input_value'] or 0., 1.))
         self.quantized = q
+        # ---- losses (forward(return_loss=True), reference M:1705-1722): per-rank sums on device; the facade all-reduces
+        # `lfq_sums` across ranks before the finalising launch
+        self.n_tokens = x.rows
+        self.loss_steps: List = []
+        n = self.video_in.numel()
+        self.sq_sum = ops.empty((1,), torch.float32)
+        sq_ws = ops.empty((max(1, ops.sq_diff_workspace_bytes(n) // 4),), torch.float32)
+        self.loss_steps.append(ops.sq_diff_sum(self.video_in, self.recon, n, self.sq_sum, sq_ws))
+        self.lfq_sums = self.lfq_losses = None
+        if self.train:
+            K = 1 << pm.cb_dim
+            self.lfq_sums = ops.empty((pm.ncb * K + 2,), torch.float32)
+            self.lfq_losses = ops.empty((4,), torch.float32)
+            st_ws = ops.empty((max(1, ops.lfq_stats_workspace_bytes(x.rows, pm.cb_dim, pm.ncb) // 4),), torch.float32)
+            self.loss_steps.append(ops.lfq_stats(self.prequant, x.rows, pm.cb_dim, pm.ncb, self.cfg.get('lfq_inv_temperature', 100.), 1.,
+                                                 self.lfq_sums, st_ws))
         # ---- ids -> quantized (decode_from_code_indices)
         self.ids_in = ops.empty((x.rows, pm.ncb), torch.int32 if pm.use_fsq else torch.int64)
         if pm.use_fsq:

@@ -6,8 +6,9 @@ Kept from the reference: the keyword-only constructor and its layer-spec tuple g
 ``state_dict`` key names and shapes (checkpoints load both ways), and the method surface
 ``encode / decode / tokenize / decode_from_code_indices / forward`` with the same tensor conventions
 (NCTHW video or NCHW image in, ids ``(B, T', H', W')`` int64 for LFQ / int32 for FSQ) and the same
-assertions.  Training losses, GAN / VGG, conditioning and gateloop layers are out of scope here and
-raise ``NotImplementedError``.
+assertions.  ``forward(return_loss=True)`` returns the reconstruction + quantizer auxiliary losses (forward values, computed
+on the device; use_gan=False, perceptual_loss_weight=0).  GAN / VGG losses, backward, conditioning and gateloop layers are out
+of scope here and raise ``NotImplementedError``.
 
 Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode) or
 torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode).  Default: bf16 when called
@@ -17,15 +18,23 @@ precision from the caller.
 from __future__ import annotations
 
 import pickle
+from collections import namedtuple
 from typing import Dict, Optional, Tuple
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from . import spec as S
 from .plan import PackedModel, Plan
 
 __version__ = '0.1.0'
+
+# the reference's loss containers (magvit2_pytorch.py:1024-1043; third-party LFQ LossBreakdown), same field names and order
+LossBreakdown = namedtuple('LossBreakdown', ['recon_loss', 'lfq_aux_loss', 'quantizer_loss_breakdown', 'perceptual_loss',
+                                             'adversarial_gen_loss', 'adaptive_adversarial_weight', 'multiscale_gen_losses',
+                                             'multiscale_gen_adaptive_weights'])
+QuantizerLossBreakdown = namedtuple('QuantizerLossBreakdown', ['per_sample_entropy', 'batch_entropy', 'commitment'])
 
 
 def _exists(v):
@@ -120,6 +129,12 @@ class VideoTokenizer(nn.Module):
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
             linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads)
 
+        self.use_gan = bool(use_gan)
+        self.perceptual_loss_weight = float(perceptual_loss_weight)
+        self.quantizer_aux_loss_weight = float(quantizer_aux_loss_weight)
+        self.lfq_entropy_loss_weight = float(lfq_entropy_loss_weight)
+        self.lfq_commitment_loss_weight = float(lfq_commitment_loss_weight)
+        self.lfq_diversity_gamma = float(lfq_diversity_gamma)
         self._validate_widths(channels, stages=S.parse_layers(self.cfg['layers'], init_dim, max_dim))
         self.channels = channels
         self.image_size = image_size
@@ -244,21 +259,22 @@ class VideoTokenizer(nn.Module):
             return torch.bfloat16
         return torch.float32
 
-    def _plan(self, B, T, want_prequant=False) -> Plan:
+    def _plan(self, B, T, want_prequant=False, train=False) -> Plan:
         ops = self._backend()
         dt = self._dtype()
         kpm = (dt, self._weights_version)
         if kpm not in self._packed:
             sd = {n: self.get_parameter(n) if n != 'quantizers.mask' else self.get_buffer(n) for n in self._param_names}
             self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops)
-        kp = (dt, self._weights_version, B, T, want_prequant)
+        train = bool(train) and not self.use_fsq
+        kp = (dt, self._weights_version, B, T, want_prequant or train, train)
         if kp not in self._plans:
             while len(self._plans) >= self.max_cached_plans:      # LRU: a plan owns an activation arena and up to 4 HIP graphs
                 old = next(iter(self._plans))
                 del self._plans[old]
                 for gk in [gk for gk in self._graphs if gk[0] == old]:
                     del self._graphs[gk]
-            self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant)
+            self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant, train)
         else:
             self._plans[kp] = self._plans.pop(kp)                  # most recently used last
         return self._plans[kp], kp
@@ -368,11 +384,17 @@ class VideoTokenizer(nn.Module):
                 video_contains_first_frame=True, adversarial_loss_weight=None, multiscale_adversarial_loss_weight=None,
                 return_prequant=False):
         assert (return_loss + return_codes + return_discr_loss) <= 1              # reference :1674
-        if return_loss or return_discr_loss:
-            raise NotImplementedError('training losses are outside the hot-path scope of this build (SURVEY.md §8f)')
+        if return_discr_loss:
+            raise NotImplementedError('the discriminator loss is outside the hot-path scope of this build (SURVEY.md §8f)')
+        if return_loss and (self.use_gan or self.perceptual_loss_weight > 0.):
+            raise NotImplementedError('forward(return_loss=True) covers the reconstruction + quantizer auxiliary losses only: '
+                                      'construct with use_gan=False, perceptual_loss_weight=0. (VGG / discriminators are outside '
+                                      'the hot-path scope of this build, SURVEY.md §8f)')
         assert cond is None and video_contains_first_frame
         video = self._check_video(video_or_images)
         with torch.no_grad():
+            if return_loss:
+                return self._forward_loss(video)
             plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
             plan.video_in.copy_(video)
             if return_codes and not return_recon:
@@ -387,5 +409,35 @@ class VideoTokenizer(nn.Module):
                 codes = self._ids_out(plan)
                 return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
             if return_recon_loss_only:
-                return torch.nn.functional.mse_loss(video.float(), recon), recon
+                plan.run(plan.loss_steps[:1])
+                return plan.sq_sum[0] / plan.video_in.numel(), recon
             return recon
+
+    def _forward_loss(self, video):
+        """forward(return_loss=True) (reference M:1705-1722, 1785-1817 with use_gan=False, no perceptual loss): forward values only
+        (this build has no backward).  Training mode + LFQ: the quantizer runs its straight-through forward value and the
+        entropy / commitment auxiliary loss (third-party LFQ.forward, training branch) from on-device statistics, all-reduced
+        over the default process group when one is initialised (the third-party code all-reduces the mean code distribution; here
+        every token-sum travels, so each rank reports the GLOBAL-batch auxiliary loss).  The reconstruction loss stays per
+        rank, as in the reference."""
+        train = self.training and not self.use_fsq
+        plan, key = self._plan(video.shape[0], video.shape[2], train=train)
+        plan.video_in.copy_(video)
+        self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
+        recon_loss = plan.sq_sum[0] / plan.video_in.numel()
+        zero = torch.zeros((), device=recon_loss.device)
+        if train:
+            n_tokens = plan.n_tokens
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                cnt = torch.tensor([float(n_tokens)], dtype=torch.float64, device=plan.lfq_sums.device)
+                dist.all_reduce(plan.lfq_sums)
+                dist.all_reduce(cnt)
+                n_tokens = float(cnt.item())
+            plan.run([plan.ops.lfq_losses(plan.lfq_sums, n_tokens, plan.pm.cb_dim, plan.pm.ncb, self.lfq_diversity_gamma,
+                                          self.lfq_entropy_loss_weight, self.lfq_commitment_loss_weight, plan.lfq_losses)])
+            ls = plan.lfq_losses.clone()
+            aux, breakdown = ls[3], QuantizerLossBreakdown(ls[0], ls[1], ls[2])
+        else:
+            aux, breakdown = zero, QuantizerLossBreakdown(zero, zero, zero)       # eval mode / FSQ: aux loss is zero (M:1705-1709)
+        total = recon_loss + aux * self.quantizer_aux_loss_weight
+        return total, LossBreakdown(recon_loss, aux, breakdown, zero, zero, 0., [], [])

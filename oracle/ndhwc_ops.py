@@ -416,6 +416,66 @@ class CpuOps:
         step.what = 'lfq'
         return step
 
+    def lfq_train(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
+        assert prequant is not None
+        def step(stream):
+            z = x[: rows * Cc].reshape(rows, Cc).to(self.acc) @ w_in.to(self.acc).t() + b_in.to(self.acc)
+            if clamp > 0:
+                z = (z / clamp).tanh() * clamp
+            pos = (z > 0).reshape(rows, ncb, cb_dim)
+            mask = (2 ** torch.arange(cb_dim - 1, -1, -1)).long()
+            ids[:rows].copy_((pos.long() * mask).sum(dim=-1))
+            prequant[:rows].copy_(z.float())
+            zf = z.float()
+            code = (zf + (torch.where(zf > 0, scale, -scale) - zf)).to(self.acc)        # straight-through forward value
+            o = code @ w_out.to(self.acc) + b_out.to(self.acc)
+            quantized[: rows * Cc].copy_(o.reshape(-1).to(quantized.dtype))
+        step.outs = [quantized, ids, prequant]
+        step.what = 'lfq_train'
+        return step
+
+    def lfq_stats_workspace_bytes(self, rows, cb_dim, ncb) -> int:
+        return min(rows, 512) * (ncb * (1 << cb_dim) + 2) * 4
+
+    def lfq_stats(self, prequant, rows, cb_dim, ncb, inv_temperature, scale, sums, ws):
+        def step(stream):
+            K = 1 << cb_dim
+            z = prequant[:rows].reshape(rows, ncb, cb_dim).double()
+            j = torch.arange(K)
+            bits = ((j[:, None] >> torch.arange(cb_dim - 1, -1, -1)[None, :]) & 1).double() * 2 - 1
+            logits = 2 * inv_temperature * scale * torch.einsum('ncd,kd->nck', z, bits)
+            prob = logits.softmax(dim=-1)
+            ent = (-prob * prob.clamp(min=1e-5).log()).sum()
+            q = torch.where(z > 0, scale, -scale)
+            sums[: ncb * K].copy_(prob.sum(dim=0).reshape(-1).float())
+            sums[ncb * K] = float(ent)
+            sums[ncb * K + 1] = float(((z - q) ** 2).sum())
+        step.outs = [sums]
+        step.what = 'lfq_stats'
+        return step
+
+    def lfq_losses(self, sums, n_tokens, cb_dim, ncb, gamma, w_entropy, w_commit, losses):
+        def step(stream):
+            K = 1 << cb_dim
+            avg = sums[: ncb * K].reshape(ncb, K).double() / n_tokens
+            hb = float((-avg * avg.clamp(min=1e-5).log()).sum(dim=-1).mean())
+            hs = float(sums[ncb * K]) / n_tokens / ncb
+            cm = float(sums[ncb * K + 1]) / n_tokens / (ncb * cb_dim) if w_commit > 0 else 0.
+            losses.copy_(torch.tensor([hs, hb, cm, (hs - gamma * hb) * w_entropy + cm * w_commit]))
+        step.outs = [losses]
+        step.what = 'lfq_losses'
+        return step
+
+    def sq_diff_workspace_bytes(self, n) -> int:
+        return min((n + 4095) // 4096, 1024) * 4
+
+    def sq_diff_sum(self, a, b, n, out, ws):
+        def step(stream):
+            out[0] = float(((a.reshape(-1)[:n].double() - b.reshape(-1)[:n].double()) ** 2).sum())
+        step.outs = [out]
+        step.what = 'sq_diff_sum'
+        return step
+
     def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):
         def step(stream):
             mask = (2 ** torch.arange(cb_dim - 1, -1, -1)).long()

@@ -211,7 +211,7 @@ def token_shift(x):
 
 
 # ----------------------------------------------------------------------------- quantizers
-def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1.):
+def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1., train=False):
     """third-party LFQ.forward eval path (reconstruction; see oracle/thirdparty.py)."""
     B, C = x.shape[:2]
     sp = x.shape[2:]
@@ -223,14 +223,35 @@ def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1.):
     pos = z > 0
     mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
     ids = (pos.int() * mask).sum(dim=-1)                                       # int64
-    q = torch.where(pos, torch.full_like(z, scale), torch.full_like(z, -scale)).to(x.dtype)
-    q = q.reshape(B, -1, num_codebooks * codebook_dim)
+    q = torch.where(pos, torch.full_like(z, scale), torch.full_like(z, -scale))
+    if train:
+        q = z + (q - z)                                                        # straight-through value (forward: q up to fp32 rounding)
+    q = q.to(x.dtype).reshape(B, -1, num_codebooks * codebook_dim)
     out = q @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
     out = out.transpose(1, 2).reshape(B, C, *sp)
     ids = ids.reshape(B, *sp, num_codebooks)
     if num_codebooks == 1:
         ids = ids.squeeze(-1)
     return out, ids, z.reshape(B, *sp, num_codebooks * codebook_dim)
+
+
+def lfq_train_losses(z, codebook_dim, num_codebooks, inv_temperature=100., diversity_gamma=2.5, entropy_loss_weight=0.1,
+                     commitment_loss_weight=1., scale=1.):
+    """third-party LFQ.forward TRAINING branch (reconstruction, parity unpinned; see oracle/thirdparty.py): from the
+    pre-sign activations z (..., num_codebooks * codebook_dim) -> (per_sample_entropy, batch_entropy, commit_loss, aux_loss).
+    Single-process form (torch.distributed: the token-averaged distribution is mean-all-reduced before its entropy)."""
+    z = z.reshape(-1, num_codebooks, codebook_dim).float()
+    K = 2 ** codebook_dim
+    mask = (2 ** torch.arange(codebook_dim - 1, -1, -1))
+    codebook = (((torch.arange(K)[:, None] & mask) != 0).float() * 2 - 1) * scale                # (K, d), MSB first
+    prob = (2 * inv_temperature * torch.einsum('ncd,kd->nck', z, codebook)).softmax(dim=-1)
+    ent = lambda pr: (-pr * pr.clamp(min=1e-5).log()).sum(dim=-1)
+    per_sample = ent(prob).mean()
+    batch = ent(prob.mean(dim=0)).mean()
+    q = torch.where(z > 0, torch.full_like(z, scale), torch.full_like(z, -scale))
+    commit = F.mse_loss(z, q) if commitment_loss_weight > 0 else z.new_zeros(())
+    aux = (per_sample - diversity_gamma * batch) * entropy_loss_weight + commit * commitment_loss_weight
+    return per_sample, batch, commit, aux
 
 
 def lfq_indices_to_codes(ids, p, codebook_dim, num_codebooks=1, scale=1.):
@@ -341,11 +362,11 @@ class OracleTokenizer:
             x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True))
         return x
 
-    def quantize(self, x):
+    def quantize(self, x, train=False):
         if self.use_fsq:
             q, ids, pre = fsq_quantize(x, self.p, self.fsq_levels)
         else:
-            q, ids, pre = lfq_quantize(x, self.p, self.codebook_dim, self.num_codebooks, self.clamp)
+            q, ids, pre = lfq_quantize(x, self.p, self.codebook_dim, self.num_codebooks, self.clamp, train=train)
         self._tap('prequant', pre)
         return self._tap('quantized', q), ids
 
@@ -391,5 +412,28 @@ class OracleTokenizer:
         if return_codes:
             return ids, recon
         return recon
+
+    def forward_loss(self, video, training=True, lfq_entropy_loss_weight=0.1, lfq_commitment_loss_weight=1., lfq_diversity_gamma=2.5,
+                     quantizer_aux_loss_weight=1.):
+        """M:1656-1896 with return_loss=True, no GAN, no perceptual loss (use_gan=False, perceptual_loss_weight=0):
+        total = mse(video, recon) + aux * quantizer_aux_loss_weight; aux = 0 in eval mode and for FSQ (M:1700-1705).
+        Returns (total, dict(recon_loss, aux, per_sample_entropy, batch_entropy, commitment))."""
+        if video.ndim == 4:
+            video = video.unsqueeze(2)
+        with torch.no_grad():
+            x = self.encode(video)
+            train = training and not self.use_fsq
+            self.taps = self.taps if self.taps is not None else {}
+            q, ids = self.quantize(x, train=train)
+            recon = self.decode(q)
+            recon_loss = F.mse_loss(video, recon)
+            zero = recon_loss.new_zeros(())
+            if train:
+                ps, bt, cm, aux = lfq_train_losses(self.taps['prequant'], self.codebook_dim, self.num_codebooks, diversity_gamma=lfq_diversity_gamma,
+                                                   entropy_loss_weight=lfq_entropy_loss_weight, commitment_loss_weight=lfq_commitment_loss_weight)
+            else:
+                ps = bt = cm = aux = zero
+        total = recon_loss + aux * quantizer_aux_loss_weight
+        return total, dict(recon_loss=recon_loss, aux=aux, per_sample_entropy=ps, batch_entropy=bt, commitment=cm)
 
     __call__ = forward

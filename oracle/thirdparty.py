@@ -139,7 +139,12 @@ class LFQ(nn.Module):
         return codes
 
     def forward(self, x, inv_temperature=100., return_loss_breakdown=False, mask=None):
-        assert not self.training, 'oracle restates the eval path only (training losses are out of scope, SURVEY §8f)'
+        """eval path as before; training path (RECONSTRUCTION of the upstream entropy / commitment losses, parity unpinned):
+        straight-through value x + (q - x), prob = softmax(2 * inv_temperature * x . codebook) over all 2^d codes,
+        per-sample entropy (log clamped at 1e-5) averaged over tokens and codebooks, entropy of the token-averaged
+        distribution (all-reduced mean under torch.distributed), aux = (H_sample - gamma * H_batch) * w_entropy +
+        mse(x, q) * w_commit."""
+        assert mask is None
         is_img_or_video = x.ndim >= 4
         should_transpose = self.channel_first if self.channel_first is not None else is_img_or_video
         if should_transpose:
@@ -156,7 +161,30 @@ class LFQ(nn.Module):
         codebook_value = torch.ones_like(x) * self.codebook_scale
         quantized = torch.where(x > 0, codebook_value, -codebook_value)
         indices = ((quantized > 0).int() * self.mask.int()).sum(dim=-1)   # int64, 'b n c'
-        x = quantized.type(orig_dtype)
+        per_sample_entropy = batch_entropy = commit_loss = entropy_aux_loss = self.zero
+        if self.training:
+            original_input = x
+            x = x + (quantized - x).detach()                                  # straight-through estimator
+            all_codes = torch.arange(self.codebook_size, device=x.device)
+            bits = ((all_codes[..., None].int() & self.mask.int()) != 0).float()
+            codebook = bits * self.codebook_scale * 2 - self.codebook_scale   # (K, d): every sign pattern, MSB first
+            distance = -2 * torch.einsum('...id,jd->...ij', original_input, codebook)
+            prob = (-distance * inv_temperature).softmax(dim=-1)              # (b, n, c, K)
+            prob = prob.reshape(b * n, self.num_codebooks, self.codebook_size)
+            ent = lambda pr: (-pr * pr.clamp(min=1e-5).log()).sum(dim=-1)
+            per_sample_entropy = ent(prob).mean()
+            avg_prob = prob.mean(dim=0)                                       # (c, K): distribution over the batch's tokens
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(avg_prob)
+                avg_prob = avg_prob / dist.get_world_size()
+            batch_entropy = ent(avg_prob).mean()
+            entropy_aux_loss = per_sample_entropy - self.diversity_gamma * batch_entropy
+            if self.commitment_loss_weight > 0:
+                commit_loss = F.mse_loss(original_input, quantized.detach())
+        else:
+            x = quantized
+        x = x.type(orig_dtype)
         x = x.reshape(b, n, -1)
         x = self.project_out(x)
         if should_transpose:
@@ -164,10 +192,11 @@ class LFQ(nn.Module):
             indices = indices.reshape(b, *spatial, self.num_codebooks)
         if not self.keep_num_codebooks_dim:
             indices = indices.squeeze(-1)
-        ret = Return(x, indices, self.zero)
+        aux_loss = entropy_aux_loss * self.entropy_loss_weight + commit_loss * self.commitment_loss_weight
+        ret = Return(x, indices, aux_loss)
         if not return_loss_breakdown:
             return ret
-        return ret, LossBreakdown(self.zero, self.zero, self.zero)
+        return ret, LossBreakdown(per_sample_entropy, batch_entropy, commit_loss)
 
 
 class FSQ(nn.Module):

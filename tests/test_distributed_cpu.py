@@ -83,3 +83,51 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ------------------------------------------------------------------------------- training-mode LFQ aux loss across ranks
+def _loss_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    D.init_from_env('gloo')
+    tok = VideoTokenizer(**KW, use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok.load_state_dict(init_state_dict(make_cfg(**KW), seed=0, randomize_se=True))
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.train()
+    video = torch.randn(4, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3))
+    lo, hi = D.shard_bounds(4, rank, world)
+    total, br = tok(video[lo:hi], return_loss=True)
+    qb = br.quantizer_loss_breakdown
+    q.put((rank, float(total), float(br.recon_loss), float(br.lfq_aux_loss), float(qb.per_sample_entropy), float(qb.batch_entropy),
+           float(qb.commitment)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_lfq_aux_loss_is_the_global_batch_loss():
+    """The token-summed code distribution is all-reduced: every rank reports the aux loss of the GLOBAL batch (what the
+    third-party quantizer's all-reduced mean distribution gives for equal shards), its own shard's reconstruction loss."""
+    from oracle.restate import OracleTokenizer
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sd = init_state_dict(make_cfg(**KW), seed=0, randomize_se=True)
+    video = torch.randn(4, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3))
+    orc = OracleTokenizer(sd, **make_cfg(**KW))
+    _, whole = orc.forward_loss(video, training=True)
+    for rank, total, recon, aux, ps, bt, cm in res:
+        _, part = orc.forward_loss(video[2 * rank: 2 * rank + 2], training=True)
+        assert abs(aux - float(whole['aux'])) <= 1e-5
+        assert abs(ps - float(whole['per_sample_entropy'])) <= 1e-5 and abs(bt - float(whole['batch_entropy'])) <= 1e-5
+        assert abs(cm - float(whole['commitment'])) <= 1e-5
+        assert abs(recon - float(part['recon_loss'])) <= 1e-5
+        assert abs(total - (recon + aux)) <= 1e-6
+    assert res[0][3] == res[1][3]                                    # identical on both ranks

@@ -266,3 +266,41 @@ def test_plan_cache_is_bounded():
         tok.tokenize(torch.randn(b, 3, 5, 32, 32, generator=torch.Generator().manual_seed(b)))
         assert len(tok._plans) <= 2
     assert {k[2] for k in tok._plans} == {3, 1}            # least recently used (B = 2) was dropped
+
+
+# ------------------------------------------------------------------------------- forward(return_loss=True): host logic on the CPU emulation
+LOSS_KW = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS, use_gan=False, perceptual_loss_weight=0.)
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_forward_return_loss_matches_oracle(training):
+    kw = {k: v for k, v in LOSS_KW.items() if k not in ('use_gan', 'perceptual_loss_weight')}
+    sd = init_state_dict(make_cfg(**kw), seed=5, randomize_se=True)
+    tok = VideoTokenizer(**LOSS_KW, seed=0)
+    tok.load_state_dict(sd)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.train(training)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(6))
+    total, br = tok(v, return_loss=True)
+    ototal, d = OracleTokenizer(sd, **make_cfg(**kw)).forward_loss(v, training=training)
+    assert br._fields == ('recon_loss', 'lfq_aux_loss', 'quantizer_loss_breakdown', 'perceptual_loss', 'adversarial_gen_loss',
+                          'adaptive_adversarial_weight', 'multiscale_gen_losses', 'multiscale_gen_adaptive_weights')
+    assert abs(float(total) - float(ototal)) <= 1e-5 * max(1., abs(float(ototal)))
+    assert abs(float(br.recon_loss) - float(d['recon_loss'])) <= 1e-5
+    assert abs(float(br.lfq_aux_loss) - float(d['aux'])) <= 1e-5
+    qb = br.quantizer_loss_breakdown
+    for name in ('per_sample_entropy', 'batch_entropy', 'commitment'):
+        assert abs(float(getattr(qb, name)) - float(d[name])) <= 1e-5, name
+    assert (float(br.lfq_aux_loss) != 0.) == training
+    loss, recon = tok(v, return_recon_loss_only=True)
+    assert recon.shape == v.shape and abs(float(loss) - float((recon - v).pow(2).mean())) <= 1e-6
+
+
+def test_forward_return_loss_refuses_gan_and_perceptual_terms():
+    tok = VideoTokenizer(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS, seed=0)   # reference defaults: GAN + VGG
+    tok._set_backend(CpuOps())
+    with pytest.raises(NotImplementedError):
+        tok(torch.zeros(1, 3, 5, 32, 32), return_loss=True)
+    with pytest.raises(NotImplementedError):
+        tok(torch.zeros(1, 3, 5, 32, 32), return_discr_loss=True)

@@ -55,3 +55,29 @@ def test_reference_default_init_families():
     assert torch.equal(rw[0::4], rw[1::4])
     for k in ('conv_in.conv.weight', 'encoder_layers.2.0.fn.0.conv.weight'):
         assert abs(rsd[k].abs().max().item() - sd[k].abs().max().item()) / rsd[k].abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('kw', [KW[0], KW[2], KW[1]])
+def test_forward_loss_matches_reference(kw, training):
+    """forward(return_loss=True) of the reference itself (use_gan=False, no perceptual loss; the quantizer is the third-party
+    reconstruction in oracle/thirdparty.py) against the restated loss path, training and eval mode, LFQ (1 and 2 codebooks) and FSQ."""
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=13, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    ref.train(training)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(14))
+    with torch.no_grad():
+        total, br = ref(v, return_loss=True)
+    orc = OracleTokenizer(sd, **cfg)
+    ototal, d = orc.forward_loss(v, training=training)
+    assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (float(ototal), float(total))
+    assert torch.allclose(d['recon_loss'], br.recon_loss, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(d['aux'], torch.as_tensor(br.lfq_aux_loss).float(), atol=2e-6, rtol=1e-5)
+    if training and not kw.get('use_fsq'):
+        qb = br.quantizer_loss_breakdown
+        assert torch.allclose(d['per_sample_entropy'], qb.per_sample_entropy, atol=2e-6, rtol=1e-5)
+        assert torch.allclose(d['batch_entropy'], qb.batch_entropy, atol=2e-6, rtol=1e-5)
+        assert torch.allclose(d['commitment'], qb.commitment, atol=2e-6, rtol=1e-5)
+        assert float(d['aux']) != 0.
