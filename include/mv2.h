@@ -192,6 +192,11 @@ int mv2_se_apply(int dtype, const void* y, const float* gate, const void* residu
  */
 int mv2_se_pool_fc1(int dtype, const void* y, const float* wk, float bk, const float* w1t, const float* b1,
                     float* hid, int frames, int P, int C, int hidden, int nslice, void* stream);
+/* fc1 of the two-launch form from pooling RECORDS ({max logit, sum exp, exp-weighted sums[C]} x nchunk per frame, as written by
+ * mv2_pw_se, mv2_conv3's fused epilogue or mv2_se_pool) instead of a pooling pass over the tensor.  (nchunk (C + 3) + C + 1024)
+ * floats must fit 64 KB of LDS. */
+int mv2_se_rec_fc1(const float* part, const float* w1t, const float* b1, float* hid, int frames, int C, int nchunk,
+                   int hidden, int nslice, void* stream);
 int mv2_se_fc2_apply(int dtype, const void* y, const float* hid, const float* w2t, const float* b2,
                      const void* residual, void* out, int frames, int P, int C, int hidden, int nslice,
                      void* stream);
@@ -238,6 +243,16 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
 int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
             int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+/* ResidualUnit tail at C = 128 / 256 / 512, bf16: the 1x1x1 conv + bias + ELU (reference M:937-938) and the SqueezeExcite
+ * pooling records of its output (reference M:226-231) in ONE launch (replaces mv2_conv k = 1 + mv2_se_pool).  `wp` is the
+ * C x C kernel in mv2_conv3's fragment-major order (the 1x1x1 kernel packed as mv2_conv does, then pack.py::to_frag_major).
+ * mv2_pw_se_rows: rows per record (32 or 64; one workgroup each), 0 when the shape is not eligible (dtype, C, P % rows).
+ * se_part receives rows / mv2_pw_se_rows records of C + 2 floats {max logit, sum exp, exp-weighted channel sums[C]} in row
+ * order: the record list mv2_se_gate consumes with nchunk = P / mv2_pw_se_rows.  P = rows per frame (H * W). */
+int mv2_pw_se_rows(int dtype, int64_t rows, int P, int C);
+int mv2_pw_se(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk, void* out,
+              float* se_part, int64_t rows, int P, int C, void* stream);
+
 /* Training-mode LFQ (third-party LFQ.forward with self.training, reference call site M:1705, loss weights M:1067-1072, recon loss
  * M:1722).  mv2_lfq_train = mv2_lfq with the straight-through forward value z + (q - z) (prequant is mandatory: it feeds
  * the statistics).  mv2_lfq_stats: per codebook the token-SUMMED softmax probabilities over all K = 2^cb_dim codes

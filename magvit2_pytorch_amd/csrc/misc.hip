@@ -425,6 +425,72 @@ __global__ __launch_bounds__(1024) void se_pool_fc1_kernel(const void* __restric
     }
 }
 
+// fc1 from pooling RECORDS (written by mv2_pw_se / mv2_conv3's fused epilogue / mv2_se_pool) instead of a pooling pass:
+// grid (S, frames); every block merges the frame's nchunk records (a few KB) and produces hidden/S units.
+__global__ __launch_bounds__(1024) void se_rec_fc1_kernel(const float* __restrict__ part, const float* __restrict__ w1t,
+                                                          const float* __restrict__ b1, float* __restrict__ hid, int C, int nchunk,
+                                                          int hidden, int hs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int f = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    const int R = nchunk;
+    float* wr = sm + R * (C + 2);       // R merge weights
+    float* pooled = wr + R;             // C
+    float* slab = pooled + C;           // 1024
+    const float* pf = part + (int64_t)f * nchunk * (C + 2);
+    for (int i = tid; i < R * (C + 2); i += 1024) sm[i] = pf[i];
+    __syncthreads();
+    float M = -INFINITY;
+    for (int r = 0; r < R; ++r) M = fmaxf(M, sm[r * (C + 2)]);
+    if (tid < R) { const float mr = sm[tid * (C + 2)]; wr[tid] = (mr == -INFINITY) ? 0.f : expf(mr - M); }
+    __syncthreads();
+    float S = 0.f;
+    for (int r = 0; r < R; ++r) S += sm[r * (C + 2) + 1] * wr[r];
+    const float inv_s = 1.f / S;
+    for (int c = tid; c < C; c += 1024) {
+        float o = 0.f;
+        for (int r = 0; r < R; ++r) o += sm[r * (C + 2) + 2 + c] * wr[r];
+        pooled[c] = o * inv_s;
+    }
+    __syncthreads();
+    const int KS = 1024 / hs;
+    const int kl = tid % hs, cs = tid / hs, k = sl * hs + kl;
+    const int per = (C + KS - 1) / KS;
+    float a0 = 0.f, a1 = 0.f;
+    if (k < hidden) {
+        const int c0 = cs * per, c1 = min(C, c0 + per);
+        int c = c0;
+        for (; c + 16 <= c1; c += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = w1t[(int64_t)(c + u) * hidden + k];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) { a0 += w[u] * pooled[c + u]; a1 += w[u + 1] * pooled[c + u + 1]; }
+        }
+        for (; c < c1; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
+    }
+    slab[cs * hs + kl] = a0 + a1;
+    __syncthreads();
+    if (tid < hs && k < hidden) {
+        float a = b1[k];
+        for (int q = 0; q < KS; ++q) a += slab[q * hs + tid];
+        hid[(int64_t)f * hidden + k] = a > 0.f ? a : 0.1f * a;
+    }
+}
+
+extern "C" int mv2_se_rec_fc1(const float* part, const float* w1t, const float* b1, float* hid, int frames, int C, int nchunk,
+                              int hidden, int nslice, void* stream) {
+    if (!part || !w1t || !b1 || !hid || frames <= 0 || nchunk <= 0 || nslice <= 0 || C <= 0) return MV2_EINVAL;
+    if (hidden <= 0 || hidden % nslice != 0) return MV2_EINVAL;
+    const int hs = hidden / nslice;
+    if (!is_pow2(hs) || hs > 1024) return MV2_EINVAL;
+    const size_t lds = ((size_t)nchunk * (C + 2) + nchunk + C + 1024) * sizeof(float);
+    if (lds > 64 * 1024) return MV2_EINVAL;
+    hipLaunchKernelGGL(se_rec_fc1_kernel, dim3((unsigned)nslice, (unsigned)frames), dim3(1024), lds, (hipStream_t)stream, part, w1t, b1, hid,
+                       C, nchunk, hidden, hs);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
 template <typename E>
 __global__ __launch_bounds__(1024) void se_fc2_apply_kernel(const void* __restrict__ y, const float* __restrict__ hidv,
                                                             const float* __restrict__ w2t, const float* __restrict__ b2,

@@ -55,6 +55,10 @@ _SIGS = {
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_se_rec_fc1': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    'mv2_pw_se_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    'mv2_pw_se': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                            C.c_int, C.c_void_p]),
     'mv2_lfq_train': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'mv2_lfq_stats_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     'mv2_lfq_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -182,6 +186,18 @@ class HipOps:
                 _ptr(se_wk), float(se_bk), _ptr(se_part), _ptr(out), _ptr(ws), nb(ws), _ptr(counters), nb(counters))
         keep = (desc, x, wp3, bias, wp2, bias2, se_wk, se_part, out, ws, counters)
         return _mk(fn, args, 'mv2_conv3', keep, [out, se_part])
+
+    def se_rec_fc1(self, part, w1, b1, hid, frames, Cc, nchunk, hidden, nslice):
+        fn, args = self.lib.mv2_se_rec_fc1, (_ptr(part), _ptr(w1), _ptr(b1), _ptr(hid), frames, Cc, nchunk, hidden, nslice)
+        return _mk(fn, args, 'mv2_se_rec_fc1', (part, w1, b1, hid), [hid])
+
+    def pw_se_rows(self, dt, rows, Pn, Cc) -> int:
+        return int(self.lib.mv2_pw_se_rows(dt, rows, Pn, Cc))
+
+    def pw_se(self, dt, x, wp, bias, se_wk, se_bk, out, se_part, rows, Pn, Cc):
+        fn = self.lib.mv2_pw_se
+        args = (dt, _ptr(x), _ptr(wp), _ptr(bias), _ptr(se_wk), float(se_bk), _ptr(out), _ptr(se_part), rows, Pn, Cc)
+        return _mk(fn, args, 'mv2_pw_se', (x, wp, bias, se_wk, out, se_part), [out, se_part])
 
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
         fn, args = self.lib.mv2_video_to_ndhwc, (dt, _ptr(video), _ptr(out), B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems)

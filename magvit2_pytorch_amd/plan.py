@@ -36,6 +36,7 @@ class PackedModel:
         self.convs: Dict[str, P.PackedConv] = {}
         self.f32: Dict[str, torch.Tensor] = {}
         self.hidden_pad: Dict[str, int] = {}
+        self.frag: Dict[str, torch.Tensor] = {}
 
         def put(name, pc):
             self.convs[name] = pc.to(ops.device)
@@ -47,6 +48,9 @@ class PackedModel:
             w3 = f(pre + '.fn.0.conv.weight')
             put(pre + '.k3', P.pack_conv3d(w3, f(pre + '.fn.0.conv.bias'), dtype, frag_major=P.conv3_packable(w3, dtype)))
             put(pre + '.k1', P.pack_pointwise(f(pre + '.fn.2.weight').flatten(1), f(pre + '.fn.2.bias'), dtype))
+            pc1 = self.convs[pre + '.k1']
+            if dtype == torch.bfloat16 and pc1.co in (128, 256, 512) and pc1.seg_bytes == 128 and pc1.co_pad == pc1.co:
+                self.frag[pre + '.k1'] = P.to_frag_major(pc1.wp)       # mv2_pw_se's weight image (same bytes, fragment order)
             c = sd[pre + '.fn.2.weight'].shape[0]
             self.f32[pre + '.se.wk'] = dev(f(pre + '.fn.4.to_k.weight').reshape(c).contiguous())
             self.f32[pre + '.se.bk'] = f(pre + '.fn.4.to_k.bias').reshape(())          # host scalar
@@ -334,8 +338,36 @@ class Plan:
             # mv2_conv3; bf16 at C = 64 (a workgroup owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
             fuse = self.dtype == torch.bfloat16 and pc3.co == 64 and pc1.co == pc3.co and pc1.kt == 1 and not os.environ.get('MV2_NO_FUSE_PW')
             y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and not os.environ.get('MV2_NO_FUSE_POOL') else None))
+            bp = 0
+            if not fuse and (pre + '.k1') in pm.frag and not os.environ.get('MV2_NO_PW_SE'):
+                bp = ops.pw_se_rows(self.dt, x.rows, Pn, C)
             if fuse:
                 y2 = y1
+            elif bp:
+                # conv1 + ELU + SqueezeExcite pooling records in one launch (pwse.hip); the gate + apply launches follow
+                y2 = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
+                nchunk = Pn // bp
+                part = self.arena.get(frames * nchunk * (C + 2), torch.float32)
+                steps.append(ops.pw_se(self.dt, y1.t, pm.frag[pre + '.k1'], pc1.bias, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']),
+                                       y2.t, part, x.rows, Pn, C))
+                steps[-1].label = pre + '.k1+pool'
+                self.step_flops[id(steps[-1])] = 2.0 * x.rows * C * C
+                self.step_names.append(pre + '.k1+pool')
+                self.arena.put(y1.t)
+                pw_part = (part, nchunk)
+                if two and (nchunk * (C + 3) + C + 1024) * 4 <= 64 * 1024:
+                    # small frames: fc1 from the records over hidden-unit slices, then fc2 + apply over channel slices
+                    hid = self.arena.get(frames * hidden, torch.float32)
+                    out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
+                    s1, s2 = hidden // max(16, hidden // 4), C // max(32, C // 8)
+                    steps.append(ops.se_rec_fc1(part, pm.f32[pre + '.se.w1'], pm.f32[pre + '.se.b1'], hid, frames, C, nchunk, hidden, s1))
+                    steps.append(ops.se_fc2_apply(self.dt, y2.t, hid, pm.f32[pre + '.se.w2'], pm.f32[pre + '.se.b2'], x.t, out.t,
+                                                  frames, Pn, C, hidden, s2))
+                    self.step_names += ['se_rec_fc1', 'se_fc2_apply']
+                    for t in (hid, part, y2.t, x.t):
+                        self.arena.put(t)
+                    return out
+                two = False
             else:
                 y2 = self._conv(steps, pre + '.k1', pc1, y1, act=P.ACT_ELU, check_bounds=False)
                 self.arena.put(y1.t)

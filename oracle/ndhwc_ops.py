@@ -266,6 +266,28 @@ class CpuOps:
         return step
 
     # ------------------------------------------------------------------ squeeze-excite
+    def pw_se_rows(self, dt, rows, Pn, Cc) -> int:
+        if dt != 0 or Cc not in (128, 256, 512) or rows % Pn:      # MV2_BF16 = 0
+            return 0
+        if Pn % 64 == 0 and rows // 64 >= 512:
+            return 64
+        return 32 if Pn % 32 == 0 else 0
+
+    def pw_se(self, dt, x, wp, bias, se_wk, se_bk, out, se_part, rows, Pn, Cc):
+        bp = self.pw_se_rows(dt, rows, Pn, Cc)
+        assert bp
+        def step(stream):
+            w = self._plain_from_frag_major(wp).reshape(-1, wp.shape[1], wp.shape[2])       # [steps][co][64 ch]
+            w2d = w.permute(1, 0, 2).reshape(wp.shape[1], -1)[:Cc, :Cc].to(self.acc)
+            y = x[: rows * Cc].reshape(rows, Cc).to(self.acc) @ w2d.t() + bias.to(self.acc)
+            y = torch.where(y > 0, y, torch.expm1(y.clamp(max=0)))
+            out[: rows * Cc].copy_(y.reshape(-1).to(out.dtype))
+            frames, nchunk = rows // Pn, Pn // bp
+            self.se_pool(dt, out, se_wk, se_bk, se_part, frames, Pn, Cc, nchunk)(stream)
+        step.outs = [out, se_part]
+        step.what = 'pw_se'
+        return step
+
     def se_pool(self, dt, y, wk, bk, part, frames, Pn, Cc, nchunk):
         def step(stream):
             yr = y[: frames * Pn * Cc].reshape(frames, Pn, Cc).to(self.acc)
@@ -323,6 +345,19 @@ class CpuOps:
             hid[: frames * hidden].copy_(h.reshape(-1).float())
         step.outs = [hid]
         step.what = 'se_pool_fc1'
+        return step
+
+    def se_rec_fc1(self, part, w1, b1, hid, frames, Cc, nchunk, hidden, nslice):
+        def step(stream):
+            pv = part[: frames * nchunk * (Cc + 2)].reshape(frames, nchunk, Cc + 2).to(self.acc)
+            M = pv[:, :, 0].max(dim=1).values
+            w = (pv[:, :, 0] - M[:, None]).exp()
+            S = (pv[:, :, 1] * w).sum(dim=1)
+            pooled = (pv[:, :, 2:] * w[:, :, None]).sum(dim=1) / S[:, None]
+            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc) + b1.to(self.acc), 0.1)
+            hid[: frames * hidden].copy_(h.reshape(-1).float())
+        step.outs = [hid]
+        step.what = 'se_rec_fc1'
         return step
 
     def se_fc2_apply(self, dt, y, hid, w2, b2, residual, out, frames, Pn, Cc, hidden, nslice):

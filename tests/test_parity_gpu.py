@@ -301,3 +301,37 @@ def test_larger_batch_full_size_properties():
     c1, r1 = tok(v[:1], return_codes=True, return_recon=True)
     assert (c1 != c[:1]).float().mean().item() <= 0.01
     assert (g.sample(r[:1].cpu()) - g.recon_sample).abs().mean().item() <= BF16_GATES['cfg2_video128x17'][1]
+
+
+@pytest.mark.parametrize('C,frames,P', [(128, 20, 4096), (128, 3, 96), (256, 20, 1024), (256, 2, 64), (512, 20, 256), (512, 5, 256), (512, 36, 1024)])
+def test_pw_se_kernel_vs_emulation(C, frames, P):
+    """mv2_pw_se (1x1x1 conv + ELU + SqueezeExcite pooling records, pwse.hip) against the CPU emulation: output rows within one
+    bf16 ulp of the fp32-accumulated value, records (max logit, sum exp, weighted sums) to 2e-3 relative; both row-tile sizes."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(C + frames)
+    rows = frames * P
+    x = (torch.randn(rows, C, generator=g) * 0.7).to(torch.bfloat16)
+    w = torch.randn(C, C, generator=g) / C ** 0.5
+    bias = torch.randn(C, generator=g) * 0.1
+    wk = torch.randn(C, generator=g) / C ** 0.5
+    pc = PK.pack_pointwise(w, bias, torch.bfloat16)
+    wp = PK.to_frag_major(pc.wp)
+    bp = ops.pw_se_rows(PK.MV2_BF16, rows, P, C)
+    assert bp == cpu.pw_se_rows(PK.MV2_BF16, rows, P, C) and bp in (32, 64)
+    nrec = rows // bp
+    out_c, part_c = torch.empty(rows * C, dtype=torch.bfloat16), torch.empty(nrec * (C + 2))
+    cpu.pw_se(PK.MV2_BF16, x.reshape(-1), wp, pc.bias, wk, 0.25, out_c, part_c, rows, P, C)(None)
+    dev = ops.device
+    out_g, part_g = torch.empty(rows * C, dtype=torch.bfloat16, device=dev), torch.empty(nrec * (C + 2), device=dev)
+    ops.pw_se(PK.MV2_BF16, x.reshape(-1).to(dev), wp.to(dev), pc.bias.to(dev), wk.to(dev), 0.25, out_g, part_g, rows, P, C)(ops.current_stream())
+    ops.synchronize()
+    a, b = out_g.cpu().float(), out_c.float()
+    assert ((a - b).abs() <= 2 ** -7 * b.abs() + 1e-3).all(), (a - b).abs().max()
+    assert (a != b).float().mean() < 0.02                        # roundings may differ on ties of the fp32 sum order only
+    pg, pc_ = part_g.cpu().reshape(nrec, C + 2), part_c.reshape(nrec, C + 2)
+    assert torch.allclose(pg[:, 0], pc_[:, 0], atol=2e-2)        # max logit: computed from bf16 rows that may differ by an ulp
+    # compare the records through what they are used for: normalised pooled vectors
+    assert torch.allclose(pg[:, 2:] / pg[:, 1:2], pc_[:, 2:] / pc_[:, 1:2], atol=5e-3, rtol=5e-3)
+    assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
