@@ -243,6 +243,17 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
 int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
             int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+/* Conditioning (reference AdaptiveRMSNorm M:278-323, Conv3DMod M:715-753, ResidualUnitMod M:975-988, cond stems M:1341-1353).
+ * The conditioning vector is per sample; everything derived from it is a small (B, n) fp32 matrix.
+ * mv2_cond_linear: out[b][o] = f(sum_i w[o][i] g(in[b][i]) + bias[o]);  mode 0: Linear;  mode 1: Linear + SiLU;
+ *   mode 2 (Conv3DMod demodulation): g(x) = (x + 1)^2, no bias, f(s) = rsqrt(max(s, eps)), w[o][i] = sum over taps of weight^2.
+ * mv2_scale_channels: out[row][c] = act(x[row][c] * (scale[row / rows_per_sample][c] + add)), act = MV2_ACT_NONE | MV2_ACT_ELU;
+ *   in place allowed (out == x). */
+int mv2_cond_linear(const float* in, const float* w, const float* bias, float* out, int B, int I, int O, int mode, float eps,
+                    void* stream);
+int mv2_scale_channels(int dtype, const void* x, const float* scale, void* out, int64_t rows, int64_t rows_per_sample, int C,
+                       float add, int act, void* stream);
+
 /* ResidualUnit tail at C = 128 / 256 / 512, bf16: the 1x1x1 conv + bias + ELU (reference M:937-938) and the SqueezeExcite
  * pooling records of its output (reference M:226-231) in ONE launch (replaces mv2_conv k = 1 + mv2_se_pool).  `wp` is the
  * C x C kernel in mv2_conv3's fragment-major order (the 1x1x1 kernel packed as mv2_conv does, then pack.py::to_frag_major).

@@ -1,5 +1,6 @@
 // Bandwidth-bound kernels of the hot path: API-edge layout change, RMSNorm statistics and the
 // three SqueezeExcite passes.  All loads/stores are 16-byte vectors on NDHWC rows.
+#include <algorithm>
 #include "common.h"
 
 // --------------------------------------------------------------------------- video -> padded NDHWC
@@ -631,3 +632,78 @@ extern "C" int mv2_event_record(void* ev, void* stream) { return (int)hipEventRe
 extern "C" int mv2_event_sync(void* ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
 extern "C" float mv2_event_elapsed_ms(void* a, void* b) { float ms = -1.f; if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f; return ms; }
 extern "C" void mv2_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+// --------------------------------------------------------------------------- conditioning (reference M:278-323, 715-753, 975-988, 1341-1353)
+// The conditioning vector is per SAMPLE, so everything derived from it is a (B, n) matrix of a few KB.
+//   mv2_cond_linear : out[b][o] = f(sum_i W[o][i] g(in[b][i]) + bias[o]), one wave per output.
+//       mode 0  plain Linear (to_gamma, to_cond);  mode 1  Linear + SiLU (the cond_in stems);
+//       mode 2  Conv3DMod's demodulation: g(x) = (x + 1)^2, no bias, f(s) = rsqrt(max(s, eps)) with W = sum over taps of w^2.
+//   mv2_scale_channels : out[row][c] = act(x[row][c] * (scale[b(row)][c] + add)) — AdaptiveRMSNorm's gamma / Conv3DMod's
+//       modulation on the input side (add = 0 / 1), the demodulation + ELU on the output side.
+__global__ __launch_bounds__(256) void cond_linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B, int I, int O,
+                                                          int mode, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (int64_t)B * O) return;
+    const int b = (int)(idx / O), o = (int)(idx - (int64_t)b * O);
+    float s = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        float x = in[(int64_t)b * I + i];
+        if (mode == 2) { x += 1.f; x *= x; }
+        s += w[(int64_t)o * I + i] * x;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias && mode != 2) s += bias[o];
+        if (mode == 1) s = s / (1.f + expf(-s));
+        if (mode == 2) s = rsqrtf(fmaxf(s, eps));
+        out[idx] = s;
+    }
+}
+
+extern "C" int mv2_cond_linear(const float* in, const float* w, const float* bias, float* out, int B, int I, int O, int mode, float eps,
+                               void* stream) {
+    if (!in || !w || !out || B <= 0 || I <= 0 || O <= 0 || mode < 0 || mode > 2) return MV2_EINVAL;
+    const int64_t n = (int64_t)B * O;
+    hipLaunchKernelGGL(cond_linear_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, B, I, O, mode, eps);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const void* __restrict__ x, const float* __restrict__ scale, void* __restrict__ out,
+                                                             int64_t nchunks, int64_t rows_per_sample, int C, float add, int act) {
+    constexpr int KV = E::kVec;
+    const int cpr = C / KV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / cpr;
+        const int ch = (int)(i - row * cpr);
+        const float* sc = scale + (row / rows_per_sample) * C + ch * KV;
+        float a[8];
+        Chunk<E>::unpack(((const i32x4*)x)[i], a);
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            float v = a[k] * (sc[k] + add);
+            if (act == MV2_ACT_ELU) v = Act<E>::elu(v);
+            a[k] = v;
+        }
+        ((i32x4*)out)[i] = Chunk<E>::pack(a);
+    }
+}
+
+extern "C" int mv2_scale_channels(int dtype, const void* x, const float* scale, void* out, int64_t rows, int64_t rows_per_sample, int C,
+                                  float add, int act, void* stream) {
+    if (!x || !scale || !out || rows <= 0 || rows_per_sample <= 0 || rows % rows_per_sample != 0) return MV2_EINVAL;
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    if (act != MV2_ACT_NONE && act != MV2_ACT_ELU) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (C <= 0 || C % kvec != 0) return MV2_EINVAL;
+    const int64_t nchunks = rows * (C / kvec);
+    const unsigned blocks = (unsigned)std::min<int64_t>((nchunks + 255) / 256, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((scale_channels_kernel<BF16>), dim3(blocks), dim3(256), 0, st, x, scale, out, nchunks, rows_per_sample, C, add, act);
+    else hipLaunchKernelGGL((scale_channels_kernel<F32>), dim3(blocks), dim3(256), 0, st, x, scale, out, nchunks, rows_per_sample, C, add, act);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

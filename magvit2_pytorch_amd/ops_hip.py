@@ -55,6 +55,8 @@ _SIGS = {
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_cond_linear': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    'mv2_scale_channels': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     'mv2_se_rec_fc1': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     'mv2_pw_se_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     'mv2_pw_se': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -186,6 +188,14 @@ class HipOps:
                 _ptr(se_wk), float(se_bk), _ptr(se_part), _ptr(out), _ptr(ws), nb(ws), _ptr(counters), nb(counters))
         keep = (desc, x, wp3, bias, wp2, bias2, se_wk, se_part, out, ws, counters)
         return _mk(fn, args, 'mv2_conv3', keep, [out, se_part])
+
+    def cond_linear(self, x, w, bias, out, B, I, O, mode, eps=1e-8):
+        fn, args = self.lib.mv2_cond_linear, (_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, I, O, mode, float(eps))
+        return _mk(fn, args, 'mv2_cond_linear', (x, w, bias, out), [out])
+
+    def scale_channels(self, dt, x, scale, out, rows, rows_per_sample, Cc, add, act):
+        fn, args = self.lib.mv2_scale_channels, (dt, _ptr(x), _ptr(scale), _ptr(out), rows, rows_per_sample, Cc, float(add), act)
+        return _mk(fn, args, 'mv2_scale_channels', (x, scale, out), [out])
 
     def se_rec_fc1(self, part, w1, b1, hid, frames, Cc, nchunk, hidden, nslice):
         fn, args = self.lib.mv2_se_rec_fc1, (_ptr(part), _ptr(w1), _ptr(b1), _ptr(hid), frames, Cc, nchunk, hidden, nslice)

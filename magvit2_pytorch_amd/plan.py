@@ -21,7 +21,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import pack as P
-from .spec import Stage, parse_layers, se_hidden, ff_inner
+from .spec import Stage, parse_layers, se_hidden, ff_inner, has_cond, cond_expanded
 
 
 class PackedModel:
@@ -60,16 +60,32 @@ class PackedModel:
             self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous())
             self.f32[pre + '.se.b2'] = dev(f(pre + '.fn.4.net.2.bias'))
 
-        def feed_forward(pre, dim, token_shift):
-            g = f(pre + '.norm.gamma').reshape(dim) * (dim ** 0.5)
+        def adaptive(pre, dim):
+            # AdaptiveRMSNorm (reference M:278-323): gamma = to_gamma(cond) is per sample, so only sqrt(dim) folds into the weights
+            self.f32[pre + '.to_gamma.w'] = dev(f(pre + '.to_gamma.weight').contiguous())
+            self.f32[pre + '.to_gamma.b'] = dev(f(pre + '.to_gamma.bias'))
+            return torch.full((dim,), dim ** 0.5)
+
+        def feed_forward(pre, dim, token_shift, cond=False):
+            g = adaptive(pre + '.norm', dim) if cond else f(pre + '.norm.gamma').reshape(dim) * (dim ** 0.5)
             pc, hp = P.pack_geglu_in(f(pre + '.net.0.weight').flatten(1), f(pre + '.net.0.bias'), dtype, in_scale=g,
                                      token_shift=token_shift)
             put(pre + '.ff1', pc)
             self.hidden_pad[pre] = hp
             put(pre + '.ff2', P.pack_pointwise(f(pre + '.net.2.weight').flatten(1), f(pre + '.net.2.bias'), dtype, k_pad=hp))
 
-        def attention(pre, dim, token_shift):
-            g = f(pre + '.norm.gamma') * (dim ** 0.5)
+        def residual_unit_mod(pre):
+            # ResidualUnitMod / Conv3DMod (reference M:680-753, 946-988): shared weights, per-sample input modulation and
+            # output demodulation; wsq[o][i] = sum over taps of w^2 feeds the demodulation factors
+            w3 = f(pre + '.conv.weights')
+            put(pre + '.k3', P.pack_conv3d(w3, torch.zeros(w3.shape[0]), dtype, frag_major=P.conv3_packable(w3, dtype)))
+            put(pre + '.k1', P.pack_pointwise(f(pre + '.conv_out.weight').flatten(1), f(pre + '.conv_out.bias'), dtype))
+            self.f32[pre + '.wsq'] = dev(w3.pow(2).sum(dim=(2, 3, 4)).contiguous())
+            self.f32[pre + '.to_cond.w'] = dev(f(pre + '.to_cond.weight').contiguous())
+            self.f32[pre + '.to_cond.b'] = dev(f(pre + '.to_cond.bias'))
+
+        def attention(pre, dim, token_shift, cond=False):
+            g = adaptive(pre + '.norm', dim) if cond else f(pre + '.norm.gamma') * (dim ** 0.5)
             packer = P.pack_token_shift if token_shift else P.pack_pointwise
             put(pre + '.qkv', packer(f(pre + '.to_qkv.0.weight'), None, dtype, in_scale=g))
             put(pre + '.out', P.pack_pointwise(f(pre + '.to_out.1.weight'), None, dtype))
@@ -109,6 +125,20 @@ class PackedModel:
                 elif st.kind == 'attend_time':
                     attention(pre + '.0.fn.fn', st.dim, True)
                     feed_forward(pre + '.1.fn.fn', st.dim, True)
+                elif st.kind == 'cond_residual':
+                    residual_unit_mod(pre)
+                elif st.kind == 'cond_attend_space':
+                    attention(pre + '.0.fn', st.dim, False, cond=True)
+                    feed_forward(pre + '.1.fn', st.dim, False, cond=True)
+                elif st.kind == 'cond_attend_time':
+                    attention(pre + '.0.fn.fn', st.dim, True, cond=True)
+                    feed_forward(pre + '.1.fn.fn', st.dim, True, cond=True)
+        self.has_cond = has_cond(cfg)
+        if self.has_cond:
+            self.dim_cond, self.dim_cond_e = cfg['dim_cond'], cond_expanded(cfg)
+            for which in ('encoder_cond_in', 'decoder_cond_in'):
+                self.f32[which + '.w'] = dev(f(which + '.0.weight').contiguous())
+                self.f32[which + '.b'] = dev(f(which + '.0.bias'))
 
         # quantizer (fp32 weights; per-token wave kernels)
         self.latent_dim = self.stages[-1].dim_out if self.stages else cfg['init_dim']
@@ -196,6 +226,12 @@ class Plan:
         # static I/O
         self.video_in = ops.empty((B, ch, T, H, W), torch.float32)
         self.recon = ops.empty((B, ch, T, H, W), torch.float32)
+        # conditioning: the caller's (B, dim_cond) vector and the two stem outputs (reference M:1341-1353, 1545-1548, 1613-1616)
+        self.cond_in = self.cond_e = self.cond_d = None
+        if pm.has_cond:
+            self.cond_in = ops.empty((B, pm.dim_cond), torch.float32)
+            self.cond_e = ops.empty((B, pm.dim_cond_e), torch.float32)
+            self.cond_d = ops.empty((B, pm.dim_cond_e), torch.float32)
         # ---- encode
         self.enc_steps: List = []
         x = self._lower_encode(self.enc_steps)
@@ -276,7 +312,7 @@ class Plan:
             self.arena.put(ws)
         return out
 
-    def _conv3(self, steps, pre, x: Act, k, fuse_k1: bool, se_part_for=None):
+    def _conv3(self, steps, pre, x: Act, k, fuse_k1: bool, se_part_for=None, act=P.ACT_ELU):
         """The ResidualUnit's k x 3 x 3 causal conv + ELU through mv2_conv3; with fuse_k1 also the 1x1x1 conv + ELU (and, with
         se_part_for, the SqueezeExcite pooling partials of that unit) in the same launch.
         Returns (output, (partials, records per frame) or None)."""
@@ -284,7 +320,7 @@ class Plan:
         pc, pc2 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1,
                  sw=1, pt=k - 1, ph=k // 2, pw=k // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes,
-                 check_bounds=1, act=P.ACT_ELU, store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
+                 check_bounds=1, act=act, store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
         assert ops.conv3_eligible(d), 'fragment-major weights but the descriptor is not mv2_conv3-eligible'
         out = Act(self.arena.get(x.rows * pc.co, self.dtype), x.B, x.T, x.H, x.W, pc.co)
         ws_bytes, cnt_bytes = ops.conv3_sizes(d)
@@ -405,23 +441,65 @@ class Plan:
             self.arena.put(t)
         return out
 
-    def _feed_forward(self, steps, pre, x: Act, shift: bool) -> Act:
+    def _modulated(self, steps, pre, x: Act, cond, w_key, b_key, add) -> Act:
+        """x * (Linear(cond) + add) per sample and channel (AdaptiveRMSNorm's gamma, Conv3DMod's input modulation)."""
+        pm, ops = self.pm, self.ops
+        g = self.arena.get(x.B * x.C, torch.float32)
+        steps.append(ops.cond_linear(cond, pm.f32[pre + w_key], pm.f32[pre + b_key], g, x.B, pm.dim_cond_e, x.C, 0))
+        xs = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
+        steps.append(ops.scale_channels(self.dt, x.t, g, xs.t, x.rows, x.T * x.H * x.W, x.C, add, P.ACT_NONE))
+        self.step_names += ['cond_linear', 'scale_channels']
+        return xs, g
+
+    def _residual_unit_mod(self, steps, pre, x: Act, cond) -> Act:
+        """ResidualUnitMod (reference M:975-988): x + ELU(conv_out(ELU(demod * conv3(x * (to_cond(cond) + 1)))))."""
+        pm, ops = self.pm, self.ops
+        k = self.cfg['residual_conv_kernel_size']
+        pc3, pc1 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
+        xs, c = self._modulated(steps, pre, x, cond, '.to_cond.w', '.to_cond.b', 1.)
+        if pc3.frag_major:
+            y1, _ = self._conv3(steps, pre, xs, k, False, act=P.ACT_NONE)
+        else:
+            y1 = self._conv(steps, pre + '.k3', pc3, xs, pt=k - 1, ph=k // 2, pw=k // 2)
+        self.arena.put(xs.t)
+        dm = self.arena.get(x.B * x.C, torch.float32)
+        steps.append(ops.cond_linear(c, pm.f32[pre + '.wsq'], None, dm, x.B, x.C, x.C, 2, 1e-8))
+        steps.append(ops.scale_channels(self.dt, y1.t, dm, y1.t, x.rows, x.T * x.H * x.W, x.C, 0., P.ACT_ELU))
+        self.step_names += ['cond_linear', 'scale_channels']
+        out = self._conv(steps, pre + '.k1', pc1, y1, act=P.ACT_ELU, residual=x, check_bounds=False)
+        for t in (c, dm, y1.t, x.t):
+            self.arena.put(t)
+        return out
+
+    def _feed_forward(self, steps, pre, x: Act, shift: bool, cond=None) -> Act:
         pm = self.pm
         rs = self._rms(steps, x, shift)
         kw = dict(pt=1, check_bounds=True) if shift else dict(check_bounds=False)
-        h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], x, act=P.ACT_GEGLU, rowscale=rs, **kw)
+        xin = x
+        if cond is not None:
+            xin, g = self._modulated(steps, pre + '.norm', x, cond, '.to_gamma.w', '.to_gamma.b', 0.)
+            self.arena.put(g)
+        h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], xin, act=P.ACT_GEGLU, rowscale=rs, **kw)
+        if cond is not None:
+            self.arena.put(xin.t)
         self.arena.put(rs)
         out = self._conv(steps, pre + '.ff2', pm.convs[pre + '.ff2'], h, residual=x, check_bounds=False)
         self.arena.put(h.t)
         self.arena.put(x.t)
         return out
 
-    def _attention(self, steps, pre, x: Act, time_axis: bool) -> Act:
+    def _attention(self, steps, pre, x: Act, time_axis: bool, cond=None) -> Act:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['attn_heads'], cfg['attn_dim_head']
         rs = self._rms(steps, x, time_axis)
         kw = dict(pt=1, check_bounds=True) if time_axis else dict(check_bounds=False)
-        qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], x, rowscale=rs, **kw)
+        xin = x
+        if cond is not None:
+            xin, g = self._modulated(steps, pre + '.norm', x, cond, '.to_gamma.w', '.to_gamma.b', 0.)
+            self.arena.put(g)
+        qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], xin, rowscale=rs, **kw)
+        if cond is not None:
+            self.arena.put(xin.t)
         self.arena.put(rs)
         ao = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
         mem = pm.f32[pre + '.mem_kv']
@@ -466,6 +544,10 @@ class Plan:
         B, T, H, W = self.B, self.T, self.H, self.W
         kt, kh, kw = cfg['input_conv_kernel_size']
         assert kh == kw and kh % 2 == 1
+        if pm.has_cond:
+            steps.append(ops.cond_linear(self.cond_in, pm.f32['encoder_cond_in.w'], pm.f32['encoder_cond_in.b'], self.cond_e, B,
+                                         pm.dim_cond, pm.dim_cond_e, 1))
+            self.step_names.append('cond_in')
         pad_t, pad_hw, cp = self.time_padding + (kt - 1), kh // 2, pm.c_in_pad
         Tp, Hp, Wp = T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw
         tail = 64 * cp
@@ -511,6 +593,15 @@ class Plan:
         if st.kind == 'attend_time':
             x = self._attention(steps, pre + '.0.fn.fn', x, True)
             return self._feed_forward(steps, pre + '.1.fn.fn', x, True)
+        cond = self.cond_e if enc else self.cond_d
+        if st.kind == 'cond_residual':
+            return self._residual_unit_mod(steps, pre, x, cond)
+        if st.kind == 'cond_attend_space':
+            x = self._attention(steps, pre + '.0.fn', x, False, cond=cond)
+            return self._feed_forward(steps, pre + '.1.fn', x, False, cond=cond)
+        if st.kind == 'cond_attend_time':
+            x = self._attention(steps, pre + '.0.fn.fn', x, True, cond=cond)
+            return self._feed_forward(steps, pre + '.1.fn.fn', x, True, cond=cond)
         raise ValueError(st.kind)
 
     def _lower_decode(self, steps, q: Act):
@@ -518,6 +609,10 @@ class Plan:
         # The decoder recycles its input buffer like any other activation: every decode is preceded by a
         # step that rewrites `quantized` (the quantizer, the ids->codes kernel, or an explicit copy).
         x = Act(q.t, q.B, q.T, q.H, q.W, q.C)
+        if pm.has_cond:
+            steps.append(self.ops.cond_linear(self.cond_in, pm.f32['decoder_cond_in.w'], pm.f32['decoder_cond_in.b'], self.cond_d, self.B,
+                                              pm.dim_cond, pm.dim_cond_e, 1))
+            self.step_names.append('cond_in')
         for st in reversed(pm.stages):
             x = self._stage(steps, st, st.dec_prefix, x, False)
         kt, kh, kw = cfg['output_conv_kernel_size']

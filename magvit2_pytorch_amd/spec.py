@@ -11,8 +11,11 @@ contract a drop-in must keep.  This module turns the same tuple
     reference checkpoint loads unchanged and ours loads into the reference.
 
 Scoped layer types: residual, consecutive_residual, compress_space, compress_time,
-attend_space, linear_attend_space, attend_time.  The conditioned (``cond_*``) and
-``gateloop_time`` layers are out of scope this round and raise.
+attend_space, linear_attend_space, attend_time, and the conditioned cond_residual (ResidualUnitMod /
+Conv3DMod, reference :680-753, :946-988), cond_attend_space, cond_attend_time (AdaptiveRMSNorm,
+reference :278-323).  ``cond_linear_attend_space`` cannot be constructed by the reference itself
+(LinearAttention.__init__ rejects the ``flash`` keyword, :1268-1279) and ``gateloop_time`` needs a
+package that is absent here: both raise.
 """
 from __future__ import annotations
 
@@ -23,8 +26,9 @@ from typing import List, Tuple
 import torch
 
 SCOPED = ('residual', 'consecutive_residual', 'compress_space', 'compress_time',
-          'attend_space', 'linear_attend_space', 'attend_time')
-UNSCOPED = ('cond_residual', 'cond_attend_space', 'cond_linear_attend_space', 'cond_attend_time', 'gateloop_time')
+          'attend_space', 'linear_attend_space', 'attend_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time')
+COND = ('cond_residual', 'cond_attend_space', 'cond_attend_time')
+UNSCOPED = ('cond_linear_attend_space', 'gateloop_time')
 
 
 @dataclass
@@ -58,6 +62,14 @@ def parse_layers(layers, init_dim, max_dim) -> List[Stage]:
         stages.append(Stage(kind, i, dim, dim_out, n, f'encoder_layers.{i}', f'decoder_layers.{n_layers - 1 - i}'))
         dim = dim_out
     return stages
+
+
+def has_cond(cfg) -> bool:
+    return any((ld[0] if isinstance(ld, tuple) else ld) in COND for ld in cfg['layers'])
+
+
+def cond_expanded(cfg) -> int:
+    return int(cfg['dim_cond'] * cfg.get('dim_cond_expansion_factor', 4.))       # reference :1155, :1345
 
 
 def ff_inner(dim, mult=4):
@@ -98,18 +110,32 @@ def _residual_unit(pre, dim, k):
     return sp
 
 
-def _feed_forward(pre, dim):
+def _adaptive_norm(pre, dim, dim_cond):
+    # AdaptiveRMSNorm: to_gamma = Linear(dim_cond, dim), weight 0 / bias 1 (reference :296-300); no to_bias on this path
+    return [ParamSpec(pre + '.to_gamma.weight', (dim, dim_cond), ('zeros',)), ParamSpec(pre + '.to_gamma.bias', (dim,), ('ones',))]
+
+
+def _residual_unit_mod(pre, dim, k, dim_cond):
+    # ResidualUnitMod (reference :946-988): to_cond Linear, Conv3DMod.weights (kaiming_normal_, fan_in, selu gain 3/4), conv_out 1x1x1
+    fan_in = dim * k * k * k
+    sp = _conv(pre + '.to_cond', (dim, dim_cond))
+    sp += [ParamSpec(pre + '.conv.weights', (dim, dim, k, k, k), ('normal', 0.75 / math.sqrt(fan_in)))]
+    sp += _conv(pre + '.conv_out', (dim, dim, 1, 1, 1))
+    return sp
+
+
+def _feed_forward(pre, dim, dim_cond=None):
     inner = ff_inner(dim)
-    sp = [ParamSpec(pre + '.norm.gamma', (dim, 1, 1, 1), ('ones',))]
+    sp = [ParamSpec(pre + '.norm.gamma', (dim, 1, 1, 1), ('ones',))] if dim_cond is None else _adaptive_norm(pre + '.norm', dim, dim_cond)
     sp += _conv(pre + '.net.0', (inner * 2, dim, 1, 1, 1))
     sp += _conv(pre + '.net.2', (dim, inner, 1, 1, 1))
     return sp
 
 
-def _attention(pre, dim, heads, dim_head, num_mem_kv=4):
+def _attention(pre, dim, heads, dim_head, num_mem_kv=4, dim_cond=None):
     inner = heads * dim_head
-    sp = [ParamSpec(pre + '.mem_kv', (2, heads, num_mem_kv, dim_head), ('randn',)),
-          ParamSpec(pre + '.norm.gamma', (dim,), ('ones',))]
+    sp = [ParamSpec(pre + '.mem_kv', (2, heads, num_mem_kv, dim_head), ('randn',))]
+    sp += [ParamSpec(pre + '.norm.gamma', (dim,), ('ones',))] if dim_cond is None else _adaptive_norm(pre + '.norm', dim, dim_cond)
     sp += _conv(pre + '.to_qkv.0', (inner * 3, dim), bias=False)
     sp += _conv(pre + '.to_out.1', (dim, inner), bias=False)
     return sp
@@ -159,11 +185,22 @@ def param_specs(cfg) -> List[ParamSpec]:
             elif st.kind == 'attend_time':
                 sp += _attention(pre + '.0.fn.fn', st.dim, cfg['attn_heads'], cfg['attn_dim_head'])
                 sp += _feed_forward(pre + '.1.fn.fn', st.dim)
+            elif st.kind == 'cond_residual':
+                sp += _residual_unit_mod(pre, st.dim, k, cond_expanded(cfg))
+            elif st.kind == 'cond_attend_space':      # AdaptiveRMSNorm is built with the RAW dim_cond (reference :1247-1254)
+                sp += _attention(pre + '.0.fn', st.dim, cfg['attn_heads'], cfg['attn_dim_head'], dim_cond=cfg['dim_cond'])
+                sp += _feed_forward(pre + '.1.fn', st.dim, dim_cond=cfg['dim_cond'])
+            elif st.kind == 'cond_attend_time':
+                sp += _attention(pre + '.0.fn.fn', st.dim, cfg['attn_heads'], cfg['attn_dim_head'], dim_cond=cfg['dim_cond'])
+                sp += _feed_forward(pre + '.1.fn.fn', st.dim, dim_cond=cfg['dim_cond'])
     dim = stages[-1].dim_out if stages else cfg['init_dim']
     # trailing LayerNorm: registered (keys exist) but never executed (reference :1322-1326, :1565)
     n = len(stages)
     sp += [ParamSpec(f'encoder_layers.{n}.1.weight', (dim,), ('ones',)),
            ParamSpec(f'encoder_layers.{n}.1.bias', (dim,), ('zeros',))]
+    if has_cond(cfg):                                                # MLP stems (reference :1341-1353)
+        sp += _conv('encoder_cond_in.0', (cond_expanded(cfg), cfg['dim_cond']))
+        sp += _conv('decoder_cond_in.0', (cond_expanded(cfg), cfg['dim_cond']))
     sp += _conv('conv_out.conv', (ch, cfg['init_dim'], *cfg['output_conv_kernel_size']))
     # quantizer (third-party key names)
     if cfg['use_fsq']:
@@ -191,6 +228,8 @@ def init_tensor(spec: ParamSpec, gen: torch.Generator) -> torch.Tensor:
         return torch.full(spec.shape, float(spec.init[1]))
     if kind == 'randn':
         return torch.randn(spec.shape, generator=gen)
+    if kind == 'normal':
+        return torch.randn(spec.shape, generator=gen) * spec.init[1]
     if kind == 'shuffle_up':    # kaiming_uniform_ (a=0) on out/r rows, each repeated r times consecutively
         fan_in, r = spec.init[1], spec.init[2]
         b = math.sqrt(6.0 / fan_in)
@@ -214,6 +253,8 @@ def init_state_dict(cfg, seed=0, randomize_se=False):
             t = torch.randn(s.shape, generator=gen) * 0.05
         if randomize_se and s.name.endswith('fn.4.net.2.bias'):
             t = torch.zeros(s.shape)
+        if randomize_se and s.name.endswith('to_gamma.weight'):      # AdaptiveRMSNorm starts at gamma = 1 for every cond (:296-297)
+            t = torch.randn(s.shape, generator=gen) * 0.05
         sd[s.name] = t
     return sd
 
@@ -222,7 +263,7 @@ DEFAULT_CFG = dict(
     layers=('residual', 'residual', 'residual'), residual_conv_kernel_size=3, num_codebooks=1, codebook_size=None,
     channels=3, init_dim=64, max_dim=float('inf'), input_conv_kernel_size=(7, 7, 7), output_conv_kernel_size=(3, 3, 3),
     pad_mode='constant', lfq_soft_clamp_input_value=10., use_fsq=False, fsq_levels=None, attn_dim_head=32,
-    attn_heads=8, linear_attn_dim_head=8, linear_attn_heads=16,
+    attn_heads=8, linear_attn_dim_head=8, linear_attn_heads=16, dim_cond=None, dim_cond_expansion_factor=4.,
 )
 
 README_LAYERS = (

@@ -105,8 +105,6 @@ class VideoTokenizer(nn.Module):
         except Exception:
             self._configs = None
 
-        if _exists(dim_cond):
-            raise NotImplementedError('conditioned layers (dim_cond) are outside the hot-path scope of this build')
         if separate_first_frame_encoding:
             raise NotImplementedError('separate_first_frame_encoding is outside the hot-path scope of this build')
         if pad_mode != 'constant':
@@ -127,7 +125,18 @@ class VideoTokenizer(nn.Module):
             input_conv_kernel_size=tuple(input_conv_kernel_size), output_conv_kernel_size=tuple(output_conv_kernel_size),
             lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
-            linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads)
+            linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads, dim_cond=dim_cond,
+            dim_cond_expansion_factor=dim_cond_expansion_factor)
+        self.has_cond = S.has_cond(self.cfg)
+        self.dim_cond = dim_cond
+        if self.has_cond:
+            assert _exists(dim_cond), 'dim_cond must be passed into VideoTokenizer, if tokenizer is to be conditioned'   # reference :1151
+            kinds = [ld[0] if isinstance(ld, tuple) else ld for ld in layers]
+            if any(k in ('cond_attend_space', 'cond_attend_time') for k in kinds) and S.cond_expanded(self.cfg) != dim_cond:
+                # the reference builds these layers' AdaptiveRMSNorm on the RAW dim_cond (:1247-1254) but feeds them the expanded
+                # vector of the stem (:1345-1353): shapes only agree when the expansion factor is 1
+                raise ValueError('cond_attend_space / cond_attend_time need dim_cond_expansion_factor=1 (AdaptiveRMSNorm is built '
+                                 'on dim_cond, the cond stems emit dim_cond * dim_cond_expansion_factor)')
 
         self.use_gan = bool(use_gan)
         self.perceptual_loss_weight = float(perceptual_loss_weight)
@@ -140,7 +149,6 @@ class VideoTokenizer(nn.Module):
         self.image_size = image_size
         self.use_fsq = use_fsq
         self.separate_first_frame_encoding = False
-        self.has_cond = False
         stages = S.parse_layers(self.cfg['layers'], init_dim, max_dim)    # raises ValueError on unknown layer (:1312)
         self.time_downsample_factor = 2 ** sum(s.kind == 'compress_time' for s in stages)
         self.time_padding = self.time_downsample_factor - 1
@@ -320,6 +328,13 @@ class VideoTokenizer(nn.Module):
         assert video.shape[1] == self.channels
         return video
 
+    def _set_cond(self, plan: Plan, cond, batch):
+        # reference :1542-1548 / :1610-1616
+        assert (not self.has_cond) or _exists(cond), '`cond` must be passed into tokenizer forward method since conditionable layers were specified'
+        if self.has_cond:
+            assert cond.shape == (batch, self.dim_cond)
+            plan.cond_in.copy_(cond)
+
     def _ids_out(self, plan: Plan):
         x = plan.latent
         ids = plan.ids.reshape(x.B, x.T, x.H, x.W, plan.pm.ncb).clone()
@@ -332,10 +347,11 @@ class VideoTokenizer(nn.Module):
     # ------------------------------------------------------------------ API
     @torch.no_grad()
     def encode(self, video, quantize=False, cond=None, video_contains_first_frame=True):
-        assert cond is None and video_contains_first_frame, 'conditioning / headless videos are out of scope'
+        assert video_contains_first_frame, 'headless videos are out of scope'
         video = self._check_video(video)
         plan, key = self._plan(video.shape[0], video.shape[2])
         plan.video_in.copy_(video)
+        self._set_cond(plan, cond, video.shape[0])
         if not quantize:
             self._run(plan, key, 'enc', [plan.enc_steps])
             return self._to_ncthw(plan.latent)
@@ -347,10 +363,11 @@ class VideoTokenizer(nn.Module):
 
     @torch.no_grad()
     def decode(self, quantized, cond=None, video_contains_first_frame=True):
-        assert cond is None and video_contains_first_frame
+        assert video_contains_first_frame
         B, C, Tl, Hl, Wl = quantized.shape
         T = (Tl - 1) * self.time_downsample_factor + 1
         plan, key = self._plan(B, T)
+        self._set_cond(plan, cond, B)
         q = plan.quantized
         assert (C, Tl, Hl, Wl) == (q.C, q.T, q.H, q.W)
         q.t[: q.rows * q.C].reshape(B, Tl, Hl, Wl, C).copy_(quantized.permute(0, 2, 3, 4, 1))
@@ -360,7 +377,7 @@ class VideoTokenizer(nn.Module):
     @torch.no_grad()
     def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):
         assert codes.dtype in (torch.long, torch.int32)                           # reference :1585
-        assert cond is None and video_contains_first_frame
+        assert video_contains_first_frame
         ncb = self.cfg['num_codebooks']
         if codes.ndim == 2:
             video_code_len = codes.shape[-1]
@@ -371,13 +388,14 @@ class VideoTokenizer(nn.Module):
         T = (Tl - 1) * self.time_downsample_factor + 1
         plan, key = self._plan(B, T)
         plan.ids_in.copy_(codes.reshape(-1, ncb))
+        self._set_cond(plan, cond, B)
         self._run(plan, key, 'codes+dec', [plan.codes_steps, plan.dec_steps])
         return plan.recon.clone()
 
     @torch.no_grad()
-    def tokenize(self, video):
+    def tokenize(self, video, cond=None):
         self.eval()
-        return self.forward(video, return_codes=True)
+        return self.forward(video, cond=cond, return_codes=True)
 
     def forward(self, video_or_images, cond=None, return_loss=False, return_codes=False, return_recon=False,
                 return_discr_loss=False, return_recon_loss_only=False, apply_gradient_penalty=True,
@@ -390,13 +408,14 @@ class VideoTokenizer(nn.Module):
             raise NotImplementedError('forward(return_loss=True) covers the reconstruction + quantizer auxiliary losses only: '
                                       'construct with use_gan=False, perceptual_loss_weight=0. (VGG / discriminators are outside '
                                       'the hot-path scope of this build, SURVEY.md §8f)')
-        assert cond is None and video_contains_first_frame
+        assert video_contains_first_frame
         video = self._check_video(video_or_images)
         with torch.no_grad():
             if return_loss:
-                return self._forward_loss(video)
+                return self._forward_loss(video, cond)
             plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
             plan.video_in.copy_(video)
+            self._set_cond(plan, cond, video.shape[0])
             if return_codes and not return_recon:
                 self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
                 codes = self._ids_out(plan)
@@ -413,7 +432,7 @@ class VideoTokenizer(nn.Module):
                 return plan.sq_sum[0] / plan.video_in.numel(), recon
             return recon
 
-    def _forward_loss(self, video):
+    def _forward_loss(self, video, cond=None):
         """forward(return_loss=True) (reference M:1705-1722, 1785-1817 with use_gan=False, no perceptual loss): forward values only
         (this build has no backward).  Training mode + LFQ: the quantizer runs its straight-through forward value and the
         entropy / commitment auxiliary loss (third-party LFQ.forward, training branch) from on-device statistics, all-reduced
@@ -423,6 +442,7 @@ class VideoTokenizer(nn.Module):
         train = self.training and not self.use_fsq
         plan, key = self._plan(video.shape[0], video.shape[2], train=train)
         plan.video_in.copy_(video)
+        self._set_cond(plan, cond, video.shape[0])
         self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
         recon_loss = plan.sq_sum[0] / plan.video_in.numel()
         zero = torch.zeros((), device=recon_loss.device)

@@ -347,6 +347,32 @@ class CpuOps:
         step.what = 'se_pool_fc1'
         return step
 
+    def cond_linear(self, x, w, bias, out, B, I, O, mode, eps=1e-8):
+        def step(stream):
+            xv = x.reshape(-1)[: B * I].reshape(B, I).double()
+            if mode == 2:
+                s_ = ((xv + 1) ** 2) @ w.double().t()
+                o = s_.clamp(min=eps).rsqrt()
+            else:
+                o = xv @ w.double().t() + (bias.double() if bias is not None else 0.)
+                if mode == 1:
+                    o = o * torch.sigmoid(o)
+            out.reshape(-1)[: B * O].copy_(o.reshape(-1).float())
+        step.outs = [out]
+        step.what = 'cond_linear'
+        return step
+
+    def scale_channels(self, dt, x, scale, out, rows, rows_per_sample, Cc, add, act):
+        def step(stream):
+            B = rows // rows_per_sample
+            v = x[: rows * Cc].reshape(B, rows_per_sample, Cc).to(self.acc) * (scale.reshape(-1)[: B * Cc].reshape(B, 1, Cc).to(self.acc) + add)
+            if act == 1:
+                v = torch.where(v > 0, v, torch.expm1(v.clamp(max=0)))
+            out[: rows * Cc].copy_(v.reshape(-1).to(out.dtype))
+        step.outs = [out]
+        step.what = 'scale_channels'
+        return step
+
     def se_rec_fc1(self, part, w1, b1, hid, frames, Cc, nchunk, hidden, nslice):
         def step(stream):
             pv = part[: frames * nchunk * (Cc + 2)].reshape(frames, nchunk, Cc + 2).to(self.acc)

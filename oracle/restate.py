@@ -40,7 +40,7 @@ def parse_layers(layers, init_dim, max_dim):
         elif kind in ('compress_space', 'compress_time'):
             dim_out = params[0] if len(params) > 0 and params[0] is not None else dim * 2
             dim_out = min(dim_out, max_dim)
-        elif kind in ('attend_space', 'linear_attend_space', 'attend_time'):
+        elif kind in ('attend_space', 'linear_attend_space', 'attend_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time'):
             pass
         else:
             raise ValueError(f'unknown / unscoped layer type {kind}')
@@ -137,10 +137,15 @@ def attend(q, k, v, causal):
     return torch.einsum('bhij,bhjd->bhid', dots.softmax(dim=-1), v)
 
 
-def attention_tokens(tok, p, pre, heads, causal):
-    """M:371-388 on tokens (b', n, C): norm -> qkv -> prepend mem_kv -> attend -> out."""
+def adaptive_gamma(cond, p, pre):
+    """AdaptiveRMSNorm M:306-323 without to_bias (the tokenizer never builds it): gamma = to_gamma(cond), (B, dim)."""
+    return cond @ p[pre + 'to_gamma.weight'].t() + p[pre + 'to_gamma.bias']
+
+
+def attention_tokens(tok, p, pre, heads, causal, gamma=None):
+    """M:371-388 on tokens (b', n, C): norm -> qkv -> prepend mem_kv -> attend -> out.  gamma (b', 1, C): AdaptiveRMSNorm."""
     b, n, C = tok.shape
-    xn = rmsnorm_last(tok, p[pre + 'norm.gamma'])
+    xn = rmsnorm_last(tok, p[pre + 'norm.gamma'] if gamma is None else gamma)
     qkv = xn @ p[pre + 'to_qkv.0.weight'].t()
     d = qkv.shape[-1] // (3 * heads)
     qkv = qkv.reshape(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)                 # qkv b h n d
@@ -153,19 +158,23 @@ def attention_tokens(tok, p, pre, heads, causal):
     return o @ p[pre + 'to_out.1.weight'].t()
 
 
-def space_attention(x, p, pre, heads):
-    """M:444-454: tokens = H*W per (b, t) frame."""
+def space_attention(x, p, pre, heads, cond=None):
+    """M:444-454: tokens = H*W per (b, t) frame.  cond (B, dim_cond): the sample's adaptive gamma for each of its frames —
+    the INTENT of 'cond_attend_space'; the reference itself only runs this with T = 1 (AdaptiveRMSNorm asserts
+    cond.shape[0] == B*T, M:309) and never through VideoTokenizer (its Sequential drops the keyword, M:1256-1259)."""
     B, C, T, H, W = x.shape
     tok = x.permute(0, 2, 3, 4, 1).reshape(B * T, H * W, C)
-    o = attention_tokens(tok, p, pre, heads, causal=False)
+    g = None if cond is None else adaptive_gamma(cond, p, pre + 'norm.').repeat_interleave(T, dim=0)[:, None, :]
+    o = attention_tokens(tok, p, pre, heads, causal=False, gamma=g)
     return o.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
 
 
-def time_attention(x, p, pre, heads):
-    """M:456-464: tokens = T per (b, h, w) pixel, causal."""
+def time_attention(x, p, pre, heads, cond=None):
+    """M:456-464: tokens = T per (b, h, w) pixel, causal.  cond: see space_attention (the reference runs it at H = W = 1 only)."""
     B, C, T, H, W = x.shape
     tok = x.permute(0, 3, 4, 2, 1).reshape(B * H * W, T, C)
-    o = attention_tokens(tok, p, pre, heads, causal=True)
+    g = None if cond is None else adaptive_gamma(cond, p, pre + 'norm.').repeat_interleave(H * W, dim=0)[:, None, :]
+    o = attention_tokens(tok, p, pre, heads, causal=True, gamma=g)
     return o.reshape(B, H, W, T, C).permute(0, 4, 3, 1, 2)
 
 
@@ -193,10 +202,31 @@ def linear_space_attention(x, p, pre, heads, dim_head):
     return o.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
 
 
-def feed_forward(x, p, pre):
-    """M:499-508 / GEGLU M:466-469: channel-first RMSNorm -> 1x1x1 -> gelu(gate) * x -> 1x1x1."""
+def conv3d_mod(x, w, cond, eps=1e-8):
+    """Conv3DMod.forward M:715-753 (StyleGAN2 modulation): per-sample weights w * (cond + 1) on the input channels, demodulated
+    to unit norm per output channel, causal zero padding, one grouped convolution."""
+    B = x.shape[0]
+    kt, kh, kw = w.shape[2:]
+    wb = w[None] * (cond[:, None, :, None, None, None] + 1)                     # (B, o, i, kt, kh, kw)
+    inv = wb.pow(2).sum(dim=(2, 3, 4, 5), keepdim=True).clamp(min=eps).rsqrt()
+    wb = (wb * inv).reshape(B * w.shape[0], *w.shape[1:])
+    xg = F.pad(x.reshape(1, B * x.shape[1], *x.shape[2:]), (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
+    return F.conv3d(xg, wb, groups=B).reshape(B, w.shape[0], *x.shape[2:])
+
+
+def residual_unit_mod(x, p, pre, cond):
+    """ResidualUnitMod.forward M:975-988: to_cond -> Conv3DMod -> ELU -> 1x1x1 -> ELU -> + x."""
+    c = cond @ p[pre + 'to_cond.weight'].t() + p[pre + 'to_cond.bias']
+    h = F.elu(conv3d_mod(x, p[pre + 'conv.weights'], c))
+    h = F.elu(F.conv3d(h, p[pre + 'conv_out.weight'], p[pre + 'conv_out.bias']))
+    return h + x
+
+
+def feed_forward(x, p, pre, cond=None):
+    """M:499-508 / GEGLU M:466-469: channel-first (Adaptive)RMSNorm -> 1x1x1 -> gelu(gate) * x -> 1x1x1."""
     C = x.shape[1]
-    xn = F.normalize(x, dim=1) * (C ** 0.5) * p[pre + 'norm.gamma']
+    gamma = p[pre + 'norm.gamma'] if cond is None else adaptive_gamma(cond, p, pre + 'norm.')[:, :, None, None, None]
+    xn = F.normalize(x, dim=1) * (C ** 0.5) * gamma
     h = F.conv3d(xn, p[pre + 'net.0.weight'], p[pre + 'net.0.bias'])
     a, gate = h.chunk(2, dim=1)
     h = F.gelu(gate) * a
@@ -303,7 +333,7 @@ class OracleTokenizer:
 
     def __init__(self, state_dict, *, image_size, layers, codebook_size=None, init_dim=64, max_dim=float('inf'),
                  channels=3, num_codebooks=1, use_fsq=False, fsq_levels=None, attn_dim_head=32, attn_heads=8,
-                 linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10.,
+                 linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10., dim_cond=None,
                  dtype=torch.float32, **_ignored):
         self.p = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone())
                   for k, v in state_dict.items() if not k.startswith('discr.')}
@@ -321,6 +351,8 @@ class OracleTokenizer:
         self.time_downsample_factor = 2 ** sum(s['kind'] == 'compress_time' for s in self.stages)
         self.time_padding = self.time_downsample_factor - 1
         self.fmap_size = image_size // (2 ** sum(s['kind'] == 'compress_space' for s in self.stages))
+        self.dim_cond = dim_cond
+        self.has_cond = any(st['kind'].startswith('cond_') for st in self.stages)
         self.taps = None            # optional dict name -> tensor for layer-wise debugging
 
     def _tap(self, name, x):
@@ -329,8 +361,24 @@ class OracleTokenizer:
         return x
 
     # stage dispatch, shared by encoder (enc=True) and decoder
-    def _stage(self, x, st, pre, enc):
+    def _cond_in(self, cond, which):
+        """M:1341-1353, 1545-1548: Linear(dim_cond, dim_cond * expansion) + SiLU, separate stems for encoder and decoder."""
+        assert (not self.has_cond) or cond is not None, '`cond` must be passed into tokenizer forward method since conditionable layers were specified'
+        if cond is None:
+            return None
+        assert cond.shape[1] == self.dim_cond
+        return F.silu(cond.to(self.dtype) @ self.p[which + '.0.weight'].t() + self.p[which + '.0.bias'])
+
+    def _stage(self, x, st, pre, enc, cond=None, cond_raw=None):
         p, kind = self.p, st['kind']
+        if kind == 'cond_residual':
+            return residual_unit_mod(x, p, pre + '.', cond)
+        if kind == 'cond_attend_space':       # AdaptiveRMSNorm is built on the raw dim_cond (M:1247-1254): needs expansion factor 1
+            x = space_attention(x, p, pre + '.0.fn.', self.attn_heads, cond=cond) + x
+            return feed_forward(x, p, pre + '.1.fn.', cond=cond) + x
+        if kind == 'cond_attend_time':
+            x = time_attention(token_shift(x), p, pre + '.0.fn.fn.', self.attn_heads, cond=cond) + x
+            return feed_forward(token_shift(x), p, pre + '.1.fn.fn.', cond=cond) + x
         if kind == 'residual':
             return residual_unit(x, p, pre + '.')
         if kind == 'consecutive_residual':
@@ -352,14 +400,15 @@ class OracleTokenizer:
             return feed_forward(token_shift(x), p, pre + '.1.fn.fn.') + x
         raise ValueError(kind)
 
-    def encode(self, video):
-        """M:1522-1576 (video_contains_first_frame=True, no cond, no separate first frame).
+    def encode(self, video, cond=None):
+        """M:1522-1576 (video_contains_first_frame=True, no separate first frame).
         NB the trailing LayerNorm of encoder_layers is never executed (zip truncation, M:1565)."""
         x = video.to(self.dtype)
         x = F.pad(x, (0, 0, 0, 0, self.time_padding, 0))                        # M:1537
         x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
+        ce = self._cond_in(cond, 'encoder_cond_in')
         for i, st in enumerate(self.stages):
-            x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True))
+            x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True, cond=ce))
         return x
 
     def quantize(self, x, train=False):
@@ -375,28 +424,29 @@ class OracleTokenizer:
             return fsq_indices_to_codes(ids, self.p, self.fsq_levels)
         return lfq_indices_to_codes(ids, self.p, self.codebook_dim, self.num_codebooks)
 
-    def decode(self, q):
+    def decode(self, q, cond=None):
         """M:1597-1649."""
         x = q
         n = len(self.stages)
+        cd = self._cond_in(cond, 'decoder_cond_in')
         for j, st in enumerate(reversed(self.stages)):
-            x = self._tap(f'dec{j}', self._stage(x, st, f'decoder_layers.{j}', False))
+            x = self._tap(f'dec{j}', self._stage(x, st, f'decoder_layers.{j}', False, cond=cd))
         x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
         return x[:, :, self.time_padding:]                                       # M:1646-1647
 
-    def decode_from_code_indices(self, codes):
+    def decode_from_code_indices(self, codes, cond=None):
         """M:1578-1595."""
         assert codes.dtype in (torch.long, torch.int32)
         if codes.ndim == 2:
             f2 = self.fmap_size ** 2
             assert codes.shape[-1] % f2 == 0
             codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
-        return self.decode(self.indices_to_codes(codes))
+        return self.decode(self.indices_to_codes(codes), cond=cond)
 
-    def tokenize(self, video):
-        return self.forward(video, return_codes=True)
+    def tokenize(self, video, cond=None):
+        return self.forward(video, cond=cond, return_codes=True)
 
-    def forward(self, video, return_codes=False, return_recon=False):
+    def forward(self, video, cond=None, return_codes=False, return_recon=False):
         """M:1656-1720 eval branches."""
         assert video.ndim in (4, 5)
         assert video.shape[-2:] == (self.image_size, self.image_size)
@@ -404,11 +454,11 @@ class OracleTokenizer:
             video = video.unsqueeze(2)
         assert (video.shape[2] - 1) % self.time_downsample_factor == 0
         with torch.no_grad():
-            x = self.encode(video)
+            x = self.encode(video, cond=cond)
             q, ids = self.quantize(x)
             if return_codes and not return_recon:
                 return ids
-            recon = self.decode(q)
+            recon = self.decode(q, cond=cond)
         if return_codes:
             return ids, recon
         return recon

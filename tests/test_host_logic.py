@@ -304,3 +304,38 @@ def test_forward_return_loss_refuses_gan_and_perceptual_terms():
         tok(torch.zeros(1, 3, 5, 32, 32), return_loss=True)
     with pytest.raises(NotImplementedError):
         tok(torch.zeros(1, 3, 5, 32, 32), return_discr_loss=True)
+
+
+# ------------------------------------------------------------------------------- conditioned layers: plan lowering on the CPU emulation
+@pytest.mark.parametrize('layers,factor', [
+    (('residual', 'compress_space', 'cond_residual', 'cond_residual'), 4.),
+    (('residual', 'compress_space', 'cond_attend_space', 'compress_time', 'cond_attend_time', 'cond_residual'), 1.)])
+def test_conditioned_layers_match_oracle(layers, factor):
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8, dim_cond_expansion_factor=factor, layers=layers)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(1))
+    cond = torch.randn(2, 8, generator=torch.Generator().manual_seed(2))
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, cond=cond, return_codes=True, return_recon=True)
+    codes, recon = tok(v, cond=cond, return_codes=True, return_recon=True)
+    assert torch.equal(codes, ocodes) and (recon - orecon).abs().max().item() <= 5e-6
+    assert (tok.decode_from_code_indices(ocodes, cond=cond) - orecon).abs().max().item() <= 5e-6
+    assert torch.equal(tok.tokenize(v, cond=cond), ocodes)
+    with pytest.raises(AssertionError):
+        tok(v, return_codes=True)                                   # reference :1542
+    with pytest.raises(AssertionError):
+        tok(v, cond=torch.zeros(2, 9), return_codes=True)           # reference :1545
+
+
+def test_conditioned_ctor_rules():
+    base = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64)
+    with pytest.raises(AssertionError):
+        VideoTokenizer(**base, layers=('residual', 'cond_residual'))                                  # dim_cond missing, reference :1151
+    with pytest.raises(ValueError):
+        VideoTokenizer(**base, dim_cond=8, layers=('residual', 'cond_attend_space'))                  # expansion factor must be 1
+    with pytest.raises(NotImplementedError):
+        VideoTokenizer(**base, dim_cond=8, layers=('residual', 'cond_linear_attend_space'))           # the reference cannot construct it
+    tok = VideoTokenizer(**base, dim_cond=8, layers=('residual', 'cond_residual'), seed=0)
+    assert tok.has_cond and 'encoder_cond_in.0.weight' in tok.state_dict() and 'encoder_layers.1.conv.weights' in tok.state_dict()

@@ -81,3 +81,59 @@ def test_forward_loss_matches_reference(kw, training):
         assert torch.allclose(d['batch_entropy'], qb.batch_entropy, atol=2e-6, rtol=1e-5)
         assert torch.allclose(d['commitment'], qb.commitment, atol=2e-6, rtol=1e-5)
         assert float(d['aux']) != 0.
+
+
+# ------------------------------------------------------------------------------- conditioned layers
+def test_cond_residual_matches_reference():
+    """ResidualUnitMod / Conv3DMod + the cond stems, end to end through the reference's own VideoTokenizer (the one conditioned
+    layer type it can execute: every layer after the first cond layer receives `cond`, M:1136-1153, 1565-1572)."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8, layers=('residual', 'compress_space', 'cond_residual', 'cond_residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    rsd = {k: v for k, v in ref.state_dict().items() if not k.startswith('discr.')}
+    assert set(rsd) == set(sd) and all(tuple(rsd[k].shape) == tuple(sd[k].shape) for k in sd)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(1))
+    cond = torch.randn(2, 8, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        codes, recon = ref(v, cond=cond, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes, cond=cond)
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, cond=cond, return_codes=True, return_recon=True)
+    assert torch.equal(ocodes, codes)
+    assert torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes, cond=cond), dec, atol=1e-5, rtol=0)
+
+
+def test_adaptive_rmsnorm_feed_forward_matches_reference_module():
+    """FeedForward(dim, dim_cond) with AdaptiveRMSNorm (channel-first, M:278-323, 471-508): the reference MODULE runs; pinned here."""
+    from oracle.ref_loader import load_reference
+    from oracle.restate import feed_forward
+    M = load_reference()
+    torch.manual_seed(0)
+    ff = M.FeedForward(32, dim_cond=8)
+    torch.nn.init.normal_(ff.norm.to_gamma.weight, std=0.3)
+    x, c = torch.randn(2, 32, 3, 4, 4), torch.randn(2, 8)
+    p = {'a.' + k: v for k, v in ff.state_dict().items()}
+    with torch.no_grad():
+        r = ff(x, cond=c)
+    assert torch.allclose(feed_forward(x, p, 'a.', cond=c), r, atol=1e-6, rtol=0)
+
+
+def test_reference_cannot_run_conditioned_attention():
+    """Documents WHY cond_attend_space / cond_attend_time are restated by intent and unpinned: the reference raises for each of them
+    (Sequential drops `cond`, M:1256-1259; AdaptiveRMSNorm's gamma (b, C) does not broadcast over tokens (b, n, C), M:323;
+    cond_linear_attend_space does not even construct, M:1268-1279)."""
+    from oracle.ref_loader import load_reference
+    M = load_reference()
+    v, cond = torch.randn(2, 3, 5, 16, 16), torch.randn(2, 8)
+    tok = make_reference_tokenizer(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8, dim_cond_expansion_factor=1.,
+                                   layers=('residual', 'compress_space', 'cond_attend_space'))
+    with pytest.raises(TypeError):
+        tok(v, cond=cond, return_codes=True)
+    sa = M.SpaceAttention(dim=32, dim_cond=8, dim_head=32, heads=8)
+    with pytest.raises(RuntimeError):
+        sa(torch.randn(2, 32, 1, 4, 4), cond=cond)
+    with pytest.raises(TypeError):
+        make_reference_tokenizer(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8, layers=('residual', 'cond_linear_attend_space'))

@@ -65,7 +65,7 @@ def margin_check(codes, ref_codes, prequant_ref, tau, max_frac):
 
 
 # ------------------------------------------------------------------------------- lockstep: every launch
-def run_lockstep(cfg, sd, v, dtype):
+def run_lockstep(cfg, sd, v, dtype, cond=None):
     """Builds the same plan for the HIP backend and for the CPU emulation of the kernel semantics,
     runs them launch by launch and compares every output buffer of every launch (teacher-forced, so a
     failure names the first wrong kernel)."""
@@ -76,6 +76,8 @@ def run_lockstep(cfg, sd, v, dtype):
     ph = Plan(PackedModel(cfg, sd, dtype, hops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
     pc = Plan(PackedModel(cfg, sd, dtype, cops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
     ph.video_in.copy_(v); pc.video_in.copy_(v)
+    if cond is not None:
+        ph.cond_in.copy_(cond); pc.cond_in.copy_(cond)
     tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
     names = list(ph.step_names)
     hsteps = ph.enc_steps + ph.q_steps + ph.dec_steps
@@ -335,3 +337,49 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     # compare the records through what they are used for: normalised pooled vectors
     assert torch.allclose(pg[:, 2:] / pg[:, 1:2], pc_[:, 2:] / pc_[:, 1:2], atol=5e-3, rtol=5e-3)
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------- conditioned layers
+COND_CASES = {
+    # ResidualUnitMod / Conv3DMod: the one conditioned layer type the reference itself can execute (pinned in test_oracle_vs_reference.py)
+    'cond_residual': dict(image_size=32, init_dim=64, max_dim=128, codebook_size=256, dim_cond=16,
+                          layers=('residual', 'compress_space', 'cond_residual', 'compress_time', 'cond_residual')),
+    # AdaptiveRMSNorm in attention + feed-forward: restated INTENT (the reference cannot run them, see oracle/restate.py)
+    'cond_attend': dict(image_size=32, init_dim=64, max_dim=256, codebook_size=256, dim_cond=16, dim_cond_expansion_factor=1.,
+                        layers=('residual', 'compress_space', 'compress_space', 'cond_attend_space', 'compress_time', 'cond_attend_time')),
+}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('name', list(COND_CASES))
+def test_lockstep_conditioned_layers(name, dtype):
+    kw = COND_CASES[name]
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=31, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(32))
+    cond = torch.randn(2, 16, generator=torch.Generator().manual_seed(33))
+    run_lockstep(cfg, sd, v, dtype, cond=cond)
+
+
+@pytest.mark.parametrize('name', list(COND_CASES))
+def test_conditioned_layers_fp32_vs_oracle(name):
+    kw = COND_CASES[name]
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=31, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(32))
+    cond = torch.randn(2, 16, generator=torch.Generator().manual_seed(33))
+    orc = OracleTokenizer(sd, **cfg)
+    orc.taps = {}
+    ocodes, orecon = orc(v, cond=cond, return_codes=True, return_recon=True)
+    tok = hip_tokenizer(kw, sd, torch.float32)
+    for rep in range(3):                                               # eager, warm, graph replay
+        codes, recon = tok(v.cuda(), cond=cond.cuda(), return_codes=True, return_recon=True)
+        margin_check(codes, ocodes, orc.taps['prequant'], 1e-4, 0.005)
+        if torch.equal(codes.cpu(), ocodes):
+            assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
+    assert (tok.decode_from_code_indices(ocodes.cuda(), cond=cond.cuda()).cpu() - orc.decode_from_code_indices(ocodes, cond=cond)).abs().max().item() <= 5e-4
+    # the conditioning is live: another cond vector changes the reconstruction
+    other = tok(v.cuda(), cond=(cond + 1.).cuda(), return_recon=True)
+    assert (other - recon).abs().max().item() > 1e-3
+    with pytest.raises(AssertionError):
+        tok(v.cuda(), return_codes=True)
