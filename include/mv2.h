@@ -243,6 +243,20 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
 int mv2_lfq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,
             const float* b_out, void* quantized, int64_t* ids, float* prequant, int64_t rows, int C,
             int cb_dim, int num_codebooks, float clamp, float scale, void* stream);
+/* ---- weight images (HOST side, host pointers): the byte-exact layouts the kernels read, from a dense fp32 kernel in the
+ * reference's state_dict order (Co, Ci, kt, kh, kw) (nn.Conv3d, magvit2_pytorch.py:894-922; Conv2d / Conv1d / Linear weights are
+ * the same call with the missing kernel dims = 1).
+ *   plain image (mv2_conv):            [step][co_pad = ceil128(Co) rows][128 bytes];  K order = taps (it, ih, iw) row-major,
+ *                                      inside a tap the Ci channels zero-padded to whole 16-byte chunks; elements of `dtype`
+ *                                      (bf16 by round-to-nearest-even); unused rows / K tail are zero.
+ *   fragment-major (mv2_conv3, mv2_pw_se; needs Ci * elem_size % 128 == 0): every group of 32 rows of a step becomes
+ *                                      [k-slice 4][half 2][row 32][16 bytes] = 16-byte chunk (2 k-slice + half) of that row.
+ * Column permutations some callers apply first (GEGLU interleave, depth-to-space order, TokenShift halves) and the RMSNorm
+ * gamma * sqrt(dim) folding are row / column re-orderings of `w` before this call: INTEGRATION.md "weight images". */
+size_t mv2_pack_conv3d_bytes(int dtype, int co, int ci, int kt, int kh, int kw);
+int mv2_pack_conv3d(int dtype, const float* w, int co, int ci, int kt, int kh, int kw, int frag_major, void* out,
+                    size_t out_bytes);
+
 /* Conditioning (reference AdaptiveRMSNorm M:278-323, Conv3DMod M:715-753, ResidualUnitMod M:975-988, cond stems M:1341-1353).
  * The conditioning vector is per sample; everything derived from it is a small (B, n) fp32 matrix.
  * mv2_cond_linear: out[b][o] = f(sum_i w[o][i] g(in[b][i]) + bias[o]);  mode 0: Linear;  mode 1: Linear + SiLU;

@@ -55,6 +55,8 @@ _SIGS = {
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    'mv2_pack_conv3d_bytes': (C.c_size_t, [C.c_int] * 6),
+    'mv2_pack_conv3d': (C.c_int, [C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_size_t]),
     'mv2_cond_linear': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     'mv2_scale_channels': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     'mv2_se_rec_fc1': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),

@@ -339,3 +339,50 @@ def test_conditioned_ctor_rules():
         VideoTokenizer(**base, dim_cond=8, layers=('residual', 'cond_linear_attend_space'))           # the reference cannot construct it
     tok = VideoTokenizer(**base, dim_cond=8, layers=('residual', 'cond_residual'), seed=0)
     assert tok.has_cond and 'encoder_cond_in.0.weight' in tok.state_dict() and 'encoder_layers.1.conv.weights' in tok.state_dict()
+
+
+# ------------------------------------------------------------------------------- weight images through the C ABI (host-side packer)
+@pytest.mark.parametrize('shape,frag', [((64, 64, 3, 3, 3), True), ((128, 64, 3, 3, 3), True), ((96, 128, 1, 3, 3), True), ((512, 512, 1, 1, 1), True),
+                                        ((64, 64, 3, 3, 3), False), ((40, 24, 3, 3, 3), False), ((3, 64, 3, 3, 3), False), ((256, 128, 1, 3, 3), False),
+                                        ((128, 64, 3, 1, 1), False), ((30, 10, 1, 1, 1), False)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_c_packer_matches_python_packer(shape, frag, dtype):
+    """mv2_pack_conv3d (host C++ behind the ABI) produces byte for byte the image pack.py builds — the layout include/mv2.h documents."""
+    import ctypes as C
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import load_library
+    lib = load_library()
+    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    if frag and not PK.conv3_packable(w, dtype):
+        frag_ok = (shape[1] * PK.esize(dtype)) % 128 == 0
+        if not frag_ok:
+            pytest.skip('not a fragment-major shape')
+    pc = PK.pack_conv3d(w, None, dtype)
+    want = PK.to_frag_major(pc.wp) if frag else pc.wp
+    dt = PK.dtype_code(dtype)
+    n = lib.mv2_pack_conv3d_bytes(dt, *shape)
+    assert n == want.numel() * want.element_size()
+    buf = (C.c_ubyte * n)()
+    wc = w.contiguous()
+    assert lib.mv2_pack_conv3d(dt, wc.data_ptr(), *shape, int(frag), C.addressof(buf), n) == 0
+    got = torch.frombuffer(buf, dtype=torch.uint8)
+    assert torch.equal(got, want.contiguous().view(torch.uint8).reshape(-1))
+    assert lib.mv2_pack_conv3d(dt, wc.data_ptr(), *shape, int(frag), C.addressof(buf), n - 1) != 0        # short buffer
+
+
+def test_c_packer_known_bytes():
+    """A hand-checkable vector (the one INTEGRATION.md prints): Co = 2, Ci = 8, one tap, bf16, w[n][c] = n * 8 + c + 1."""
+    import ctypes as C
+    from magvit2_pytorch_amd.ops_hip import load_library
+    lib = load_library()
+    w = (torch.arange(16, dtype=torch.float32) + 1).reshape(2, 8, 1, 1, 1).contiguous()
+    n = lib.mv2_pack_conv3d_bytes(0, 2, 8, 1, 1, 1)
+    assert n == 1 * 128 * 128                                        # one K step, 128 padded rows, 128 bytes each
+    buf = (C.c_ubyte * n)()
+    assert lib.mv2_pack_conv3d(0, w.data_ptr(), 2, 8, 1, 1, 1, 0, C.addressof(buf), n) == 0
+    img = torch.frombuffer(buf, dtype=torch.int16).reshape(1, 128, 64)
+    # 8 channels = one 16-byte segment: 8 segments share a 128-byte step, this conv has one -> elements 0..7 of each row
+    assert img[0, 0, :8].view(torch.bfloat16).float().tolist() == [1., 2., 3., 4., 5., 6., 7., 8.]
+    assert img[0, 1, :8].view(torch.bfloat16).float().tolist() == [9., 10., 11., 12., 13., 14., 15., 16.]
+    assert int(img[0, 0, 0]) == 0x3F80 and int(img[0, 1, 0]) == 0x4110       # bf16(1.0), bf16(9.0)
+    assert not img[0, 2:].any() and not img[0, :2, 8:].any()
