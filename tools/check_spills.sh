@@ -1,10 +1,10 @@
 #!/bin/bash
 # Lists VGPR count, scratch bytes and spill count of every kernel in magvit2_pytorch_amd/csrc (gfx950 ISA, no GPU
-# needed).  A non-zero scratch / spill column on a hot kernel is a bug: see DESIGN.md §4.1 lesson 6.
-# usage: tools/check_spills.sh [file.hip ...]        (default: all six sources; conv_halo.hip takes ~1 min)
+# needed).  A non-zero scratch / spill column on a hot kernel is a bug.
+# usage: tools/check_spills.sh [file.hip ...]        (default: the product sources)
 cd "$(dirname "$0")/../magvit2_pytorch_amd/csrc" || exit 1
 T=$(mktemp -d)
-for f in ${@:-quant.hip misc.hip attn.hip conv.hip conv_halo_rs.hip conv_halo.hip}; do
+for f in ${@:-conv3.hip pwse.hip conv.hip misc.hip attn.hip quant.hip}; do
   b=$(basename "$f" .hip)
   hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -I../../include "$b.hip" -o "$T/$b.s" 2>/dev/null || { echo "$b: compile failed"; continue; }
   grep "\.name: \+_Z\|private_segment_fixed_size\|\.vgpr_count\|vgpr_spill" "$T/$b.s" |
