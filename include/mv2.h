@@ -268,6 +268,11 @@ int mv2_cond_linear(const float* in, const float* w, const float* bias, float* o
 int mv2_scale_channels(int dtype, const void* x, const float* scale, void* out, int64_t rows, int64_t rows_per_sample, int C,
                        float add, int act, void* stream);
 
+/* Frame ranges (separate_first_frame_encoding, reference M:1553-1561, 1633-1639): dst[b][dst_t0 + t] = src ? src[b][src_t0 + t] : 0
+ * for t < nT; src (B, src_T, frame), dst (B, dst_T, frame), a frame = frame_bytes contiguous bytes (multiple of 16). */
+int mv2_copy_frames(const void* src, int src_T, int src_t0, void* dst, int dst_T, int dst_t0, int nT, int B, int64_t frame_bytes,
+                    void* stream);
+
 /* ResidualUnit tail at C = 128 / 256 / 512, bf16: the 1x1x1 conv + bias + ELU (reference M:937-938) and the SqueezeExcite
  * pooling records of its output (reference M:226-231) in ONE launch (replaces mv2_conv k = 1 + mv2_se_pool).  `wp` is the
  * C x C kernel in mv2_conv3's fragment-major order (the 1x1x1 kernel packed as mv2_conv does, then pack.py::to_frag_major).

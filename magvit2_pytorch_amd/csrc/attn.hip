@@ -339,25 +339,38 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t row = ((int64_t)f * n + t) * ld;
-        float k[8], v[9];
+    // four tokens of loads in flight: the loop used to be a chain of ~40 dependent global-load latencies per block
+    constexpr int U = 4, NC = 8 / E::kVec;
+    for (int t = t0; t < t1; t += U) {
+        i32x4 kr[U][NC], vr[U][NC];
 #pragma unroll
-        for (int c = 0; c < 8 / E::kVec; ++c) {
-            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
-            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
+        for (int u = 0; u < U; ++u) {
+            const int tu = min(t + u, t1 - 1);
+            const int64_t row = ((int64_t)f * n + tu) * ld;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                kr[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
+                vr[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
+            }
         }
-        v[8] = 1.f;
-        float ki = k[0];
 #pragma unroll
-        for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+        for (int u = 0; u < U; ++u) {
+            if (t + u >= t1) break;
+            float k[8], v[9];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
+            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kr[u][c], k + c * E::kVec); Chunk<E>::unpack(vr[u][c], v + c * E::kVec); }
+            v[8] = 1.f;
+            float ki = k[0];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const float ph = (ki * k[jj]) * r2;
+            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
+            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float ph = (ki * k[jj]) * r2;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
+            }
         }
     }
     float* dst = part + (((int64_t)f * nchunk + j) * heads + h) * TAY_S;
@@ -384,53 +397,94 @@ __global__ __launch_bounds__(256) void taylor_reduce_kernel(const float* __restr
     }
 }
 
-// block: 64 tokens of one frame; thread -> (token slot, head), loops 4 token slots
+// block: 64 tokens of one frame; thread -> (token slot, head) with FOUR tokens per thread (slots ts, ts + 16, ...): every LDS read
+// of the state (rows padded to 12 floats = three ds_read_b128) feeds 4 x 9 FMAs instead of one read per FMA.
+#define TAY_LP 12
 template <typename E>
 __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restrict__ q, const float* __restrict__ kvsum,
                                                            void* __restrict__ out, int n, int heads) {
-    extern __shared__ __attribute__((aligned(16))) float kvs[];   // heads * 657
+    extern __shared__ __attribute__((aligned(16))) float kvs[];   // heads * 73 * 12
     const int f = blockIdx.y;
     const int tot = heads * TAY_S;
-    for (int e = threadIdx.x; e < tot; e += 256) kvs[e] = kvsum[(int64_t)f * tot + e];
+    for (int e = threadIdx.x; e < tot; e += 256) {
+        const int hh = e / TAY_S, r = e - hh * TAY_S;
+        kvs[(hh * TAY_F + r / 9) * TAY_LP + r % 9] = kvsum[(int64_t)f * tot + e];
+    }
     __syncthreads();
-    const int tpb = 256 / heads;           // tokens per pass
+    const int tpb = 256 / heads;           // token slots per pass
     const int h = threadIdx.x % heads, ts = threadIdx.x / heads;
-    const float* S = kvs + h * TAY_S;
+    const float* S = kvs + h * TAY_F * TAY_LP;
     const float scale = 0.35355339059327376220f;   // 8^-0.5
     const float r2 = 0.70710678118654752440f;
     const int tile0 = blockIdx.x * 64;
-    for (int tt = ts; tt < 64; tt += tpb) {
-        const int t = tile0 + tt;
-        if (t >= n) break;
-        const int64_t row = (int64_t)f * n + t;
-        float qv[8];
+    constexpr int NT = 4, NC = 8 / E::kVec;
+    for (int base = ts; base < 64; base += tpb * NT) {
+        float qv[NT][8], acc[NT][9];
+        int tok[NT];
 #pragma unroll
-        for (int c = 0; c < 8 / E::kVec; ++c)
-            Chunk<E>::unpack(*(const i32x4*)((const char*)q + (row * heads * 8 + h * 8) * E::kBytes + c * 16), qv + c * E::kVec);
+        for (int u = 0; u < NT; ++u) {
+            tok[u] = tile0 + base + u * tpb;
+            const int tc = min(tok[u], n - 1);
+            const int64_t row = (int64_t)f * n + tc;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) qv[d] *= scale;
-        float acc[9];
+            for (int c = 0; c < NC; ++c)
+                Chunk<E>::unpack(*(const i32x4*)((const char*)q + (row * heads * 8 + h * 8) * E::kBytes + c * 16), qv[u] + c * E::kVec);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) acc[e] = S[e];            // phi_0 = 1
+            for (int d = 0; d < 8; ++d) qv[u][d] *= scale;
+        }
+        auto row9 = [&](int r, float* s9) {
+            asm volatile("" ::: "memory");                         // keep the fully unrolled loop from hoisting all 73 rows (spills)
+            const f32x4 a = *(const f32x4*)(S + r * TAY_LP), b = *(const f32x4*)(S + r * TAY_LP + 4), c = *(const f32x4*)(S + r * TAY_LP + 8);
+            s9[0] = a[0]; s9[1] = a[1]; s9[2] = a[2]; s9[3] = a[3]; s9[4] = b[0]; s9[5] = b[1]; s9[6] = b[2]; s9[7] = b[3]; s9[8] = c[0];
+        };
+        {
+            float s9[9]; row9(0, s9);                              // phi_0 = 1
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int e = 0; e < 9; ++e) acc[e] += qv[i] * S[(1 + i) * 9 + e];
+                for (int e = 0; e < 9; ++e) acc[u][e] = s9[e];
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            float s9[9]; row9(1 + i, s9);
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) acc[u][e] += qv[u][i] * s9[e];
+        }
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {                              // a real loop: unrolled, the 256 products q_i q_j were all hoisted (spills)
+            float qi[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                qi[u] = qv[u][0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) qi[u] = (i == k) ? qv[u][k] : qi[u];
+                qi[u] *= r2;
+            }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const float ph = (qv[i] * qv[jj]) * r2;
+                float s9[9]; row9(9 + 8 * i + jj, s9);
 #pragma unroll
-                for (int e = 0; e < 9; ++e) acc[e] += ph * S[(9 + 8 * i + jj) * 9 + e];
+                for (int u = 0; u < NT; ++u) {
+                    const float ph = qi[u] * qv[u][jj];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) acc[u][e] += ph * s9[e];
+                }
             }
-        const float inv = 1.f / fmaxf(acc[8], 1e-5f);
-        float o[8];
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = acc[e] * inv;
+        for (int u = 0; u < NT; ++u) {
+            if (tok[u] >= n || base + u * tpb >= 64) continue;
+            const float inv = 1.f / fmaxf(acc[u][8], 1e-5f);
+            float o[8];
 #pragma unroll
-        for (int c = 0; c < 8 / E::kVec; ++c)
-            *(i32x4*)((char*)out + (row * heads * 8 + h * 8) * E::kBytes + c * 16) = Chunk<E>::pack(o + c * E::kVec);
+            for (int e = 0; e < 8; ++e) o[e] = acc[u][e] * inv;
+            const int64_t row = (int64_t)f * n + tok[u];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                *(i32x4*)((char*)out + (row * heads * 8 + h * 8) * E::kBytes + c * 16) = Chunk<E>::pack(o + c * E::kVec);
+        }
     }
 }
 
@@ -450,7 +504,7 @@ extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, voi
                                 int heads, int nchunk, void* stream) {
     if (!q || !part || !out || !kvsum_ws || frames <= 0 || n <= 0 || heads <= 0 || 256 % heads != 0) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
-    const size_t lds = (size_t)heads * TAY_S * sizeof(float);
+    const size_t lds = (size_t)heads * TAY_F * TAY_LP * sizeof(float);
     if (lds > 64 * 1024) return MV2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0, st, part, kvsum_ws, heads, nchunk);

@@ -707,3 +707,29 @@ extern "C" int mv2_scale_channels(int dtype, const void* x, const float* scale, 
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// --------------------------------------------------------------------------- frame ranges (separate_first_frame_encoding, reference M:1553-1561, 1633-1639)
+// dst[b][dst_t0 + t][:] = src ? src[b][src_t0 + t][:] : 0   for t < nT;  a frame is frame_bytes (multiple of 16) contiguous bytes.
+// Packs [zero padding | first-frame conv | conv_in of the remaining frames] into one latent tensor and slices it again before conv_out.
+__global__ __launch_bounds__(256) void copy_frames_kernel(const i32x4* __restrict__ src, i32x4* __restrict__ dst, int64_t chunks_per_frame,
+                                                          int64_t total, int src_T, int src_t0, int dst_T, int dst_t0, int nT) {
+    const int64_t per_sample = chunks_per_frame * nT;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per_sample, r = i - b * per_sample;
+        const i32x4 zero = {0, 0, 0, 0};
+        dst[(b * dst_T + dst_t0) * chunks_per_frame + r] = src ? src[(b * src_T + src_t0) * chunks_per_frame + r] : zero;
+    }
+}
+
+extern "C" int mv2_copy_frames(const void* src, int src_T, int src_t0, void* dst, int dst_T, int dst_t0, int nT, int B, int64_t frame_bytes,
+                               void* stream) {
+    if (!dst || B <= 0 || nT <= 0 || frame_bytes <= 0 || frame_bytes % 16 != 0) return MV2_EINVAL;
+    if (dst_t0 < 0 || dst_t0 + nT > dst_T || (src && (src_t0 < 0 || src_t0 + nT > src_T))) return MV2_EINVAL;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15)) return MV2_EINVAL;
+    const int64_t cpf = frame_bytes / 16, total = cpf * nT * B;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(copy_frames_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const i32x4*)src, (i32x4*)dst, cpf, total, src_T, src_t0,
+                       dst_T, dst_t0, nT);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

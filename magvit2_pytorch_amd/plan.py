@@ -43,6 +43,10 @@ class PackedModel:
 
         put('conv_in', P.pack_conv_in(f('conv_in.conv.weight'), f('conv_in.conv.bias'), dtype, self.c_in_pad))
         put('conv_out', P.pack_conv3d(f('conv_out.conv.weight'), f('conv_out.conv.bias'), dtype))
+        self.separate_first_frame = bool(cfg.get('separate_first_frame_encoding'))
+        if self.separate_first_frame:      # SameConv2d pair = the same packers with one time tap (reference :1113-1120)
+            put('conv_in_first_frame', P.pack_conv_in(f('conv_in_first_frame.weight')[:, :, None], f('conv_in_first_frame.bias'), dtype, self.c_in_pad))
+            put('conv_out_first_frame', P.pack_conv3d(f('conv_out_first_frame.weight')[:, :, None], f('conv_out_first_frame.bias'), dtype))
 
         def residual_unit(pre):
             w3 = f(pre + '.fn.0.conv.weight')
@@ -226,6 +230,12 @@ class Plan:
         # static I/O
         self.video_in = ops.empty((B, ch, T, H, W), torch.float32)
         self.recon = ops.empty((B, ch, T, H, W), torch.float32)
+        self.sep = pm.separate_first_frame
+        if self.sep:
+            assert T >= 2, 'separate_first_frame_encoding needs at least two frames (the reference fails on a single frame: conv_in gets an empty clip)'
+            # edge buffers: the facade splits the clip into its first frame and the rest and joins the two reconstructions
+            self.video_first, self.video_rest = ops.empty((B, ch, 1, H, W), torch.float32), ops.empty((B, ch, T - 1, H, W), torch.float32)
+            self.recon_first, self.recon_rest = ops.empty((B, ch, 1, H, W), torch.float32), ops.empty((B, ch, T - 1, H, W), torch.float32)
         # conditioning: the caller's (B, dim_cond) vector and the two stem outputs (reference M:1341-1353, 1545-1548, 1613-1616)
         self.cond_in = self.cond_e = self.cond_d = None
         if pm.has_cond:
@@ -548,16 +558,37 @@ class Plan:
             steps.append(ops.cond_linear(self.cond_in, pm.f32['encoder_cond_in.w'], pm.f32['encoder_cond_in.b'], self.cond_e, B,
                                          pm.dim_cond, pm.dim_cond_e, 1))
             self.step_names.append('cond_in')
-        pad_t, pad_hw, cp = self.time_padding + (kt - 1), kh // 2, pm.c_in_pad
-        Tp, Hp, Wp = T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw
+        pad_hw, cp = kh // 2, pm.c_in_pad
+        Hp, Wp = H + 2 * pad_hw, W + 2 * pad_hw
         tail = 64 * cp
-        padded = self.arena.get(B * Tp * Hp * Wp * cp + tail, self.dtype)
-        steps.append(ops.video_to_ndhwc(self.dt, self.video_in, padded, B, cfg['channels'], T, H, W, pad_t, pad_hw, cp, tail))
-        self.step_names.append('video_to_ndhwc')
-        xin = Act(padded, B, Tp, Hp, Wp, cp)
-        x = self._conv(steps, 'conv_in', pm.convs['conv_in'], xin, To=T + self.time_padding, Ho=H, Wo=W, check_bounds=False,
-                       in_bytes=padded.numel() * padded.element_size())
-        self.arena.put(padded)
+
+        def conv_in(name, video, frames, pad_t, To):
+            Tp = frames + pad_t
+            padded = self.arena.get(B * Tp * Hp * Wp * cp + tail, self.dtype)
+            steps.append(ops.video_to_ndhwc(self.dt, video, padded, B, cfg['channels'], frames, H, W, pad_t, pad_hw, cp, tail))
+            self.step_names.append('video_to_ndhwc')
+            y = self._conv(steps, name, pm.convs[name], Act(padded, B, Tp, Hp, Wp, cp), To=To, Ho=H, Wo=W, check_bounds=False,
+                           in_bytes=padded.numel() * padded.element_size())
+            self.arena.put(padded)
+            return y
+
+        if self.sep:
+            # reference M:1553-1561: first frame through its own 2-D conv, frames 1.. through conv_in (causal zero padding right
+            # before frame 1), then [time_padding zero frames | first | rest] packed into one latent
+            tp = self.time_padding
+            ff = conv_in('conv_in_first_frame', self.video_first, 1, 0, 1)
+            rest = conv_in('conv_in', self.video_rest, T - 1, kt - 1, T - 1)
+            x = Act(self.arena.get(B * (T + tp) * H * W * ff.C, self.dtype), B, T + tp, H, W, ff.C)
+            fb = H * W * ff.C * ff.t.element_size()
+            if tp:
+                steps.append(ops.copy_frames(None, 0, 0, x.t, T + tp, 0, tp, B, fb))
+            steps.append(ops.copy_frames(ff.t, 1, 0, x.t, T + tp, tp, 1, B, fb))
+            steps.append(ops.copy_frames(rest.t, T - 1, 0, x.t, T + tp, tp + 1, T - 1, B, fb))
+            self.step_names += ['copy_frames'] * (3 if tp else 2)
+            self.arena.put(ff.t)
+            self.arena.put(rest.t)
+        else:
+            x = conv_in('conv_in', self.video_in, T, self.time_padding + (kt - 1), T + self.time_padding)
         for st in pm.stages:
             x = self._stage(steps, st, st.enc_prefix, x, True)
         return x
@@ -616,6 +647,20 @@ class Plan:
         for st in reversed(pm.stages):
             x = self._stage(steps, st, st.dec_prefix, x, False)
         kt, kh, kw = cfg['output_conv_kernel_size']
+        if self.sep:
+            # reference M:1633-1639: frame time_padding through the 2-D conv, the frames after it through conv_out
+            tp, T = self.time_padding, self.T
+            fb = x.H * x.W * x.C * x.t.element_size()
+            xff = Act(self.arena.get(x.B * x.H * x.W * x.C, self.dtype), x.B, 1, x.H, x.W, x.C)
+            xr = Act(self.arena.get(x.B * (T - 1) * x.H * x.W * x.C, self.dtype), x.B, T - 1, x.H, x.W, x.C)
+            steps.append(self.ops.copy_frames(x.t, x.T, tp, xff.t, 1, 0, 1, x.B, fb))
+            steps.append(self.ops.copy_frames(x.t, x.T, tp + 1, xr.t, T - 1, 0, T - 1, x.B, fb))
+            self.step_names += ['copy_frames'] * 2
+            self._conv(steps, 'conv_out_first_frame', pm.convs['conv_out_first_frame'], xff, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
+                       out_t=self.recon_first, out_c=4)
+            self._conv(steps, 'conv_out', pm.convs['conv_out'], xr, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
+                       out_t=self.recon_rest, out_c=4)
+            return
         self._conv(steps, 'conv_out', pm.convs['conv_out'], x, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
                    crop_t=self.time_padding, out_t=self.recon, out_c=4)
 

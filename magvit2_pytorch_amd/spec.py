@@ -157,6 +157,9 @@ def param_specs(cfg) -> List[ParamSpec]:
     ch = cfg['channels']
     sp: List[ParamSpec] = []
     sp += _conv('conv_in.conv', (cfg['init_dim'], ch, *cfg['input_conv_kernel_size']))
+    if cfg.get('separate_first_frame_encoding'):                      # SameConv2d pair (reference :1113-1120, :757-766)
+        sp += _conv('conv_in_first_frame', (cfg['init_dim'], ch, *cfg['input_conv_kernel_size'][-2:]))
+        sp += _conv('conv_out_first_frame', (ch, cfg['init_dim'], *cfg['output_conv_kernel_size'][-2:]))
     for st in stages:
         for pre, enc in ((st.enc_prefix, True), (st.dec_prefix, False)):
             if st.kind == 'residual':
@@ -264,6 +267,7 @@ DEFAULT_CFG = dict(
     channels=3, init_dim=64, max_dim=float('inf'), input_conv_kernel_size=(7, 7, 7), output_conv_kernel_size=(3, 3, 3),
     pad_mode='constant', lfq_soft_clamp_input_value=10., use_fsq=False, fsq_levels=None, attn_dim_head=32,
     attn_heads=8, linear_attn_dim_head=8, linear_attn_heads=16, dim_cond=None, dim_cond_expansion_factor=4.,
+    separate_first_frame_encoding=False,
 )
 
 README_LAYERS = (

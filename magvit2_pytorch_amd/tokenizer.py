@@ -105,8 +105,6 @@ class VideoTokenizer(nn.Module):
         except Exception:
             self._configs = None
 
-        if separate_first_frame_encoding:
-            raise NotImplementedError('separate_first_frame_encoding is outside the hot-path scope of this build')
         if pad_mode != 'constant':
             raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
         if lfq_spherical:
@@ -126,7 +124,7 @@ class VideoTokenizer(nn.Module):
             lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
             linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads, dim_cond=dim_cond,
-            dim_cond_expansion_factor=dim_cond_expansion_factor)
+            dim_cond_expansion_factor=dim_cond_expansion_factor, separate_first_frame_encoding=bool(separate_first_frame_encoding))
         self.has_cond = S.has_cond(self.cfg)
         self.dim_cond = dim_cond
         if self.has_cond:
@@ -148,7 +146,7 @@ class VideoTokenizer(nn.Module):
         self.channels = channels
         self.image_size = image_size
         self.use_fsq = use_fsq
-        self.separate_first_frame_encoding = False
+        self.separate_first_frame_encoding = bool(separate_first_frame_encoding)
         stages = S.parse_layers(self.cfg['layers'], init_dim, max_dim)    # raises ValueError on unknown layer (:1312)
         self.time_downsample_factor = 2 ** sum(s.kind == 'compress_time' for s in stages)
         self.time_padding = self.time_downsample_factor - 1
@@ -335,6 +333,17 @@ class VideoTokenizer(nn.Module):
             assert cond.shape == (batch, self.dim_cond)
             plan.cond_in.copy_(cond)
 
+    def _set_video(self, plan: Plan, video):
+        if plan.sep:          # reference M:1553-1555: the first frame and the rest go through different convolutions
+            plan.video_first.copy_(video[:, :, :1])
+            plan.video_rest.copy_(video[:, :, 1:])
+        plan.video_in.copy_(video)
+
+    def _recon_out(self, plan: Plan):
+        if plan.sep:          # reference M:1639: pack([outff, out])
+            return torch.cat((plan.recon_first, plan.recon_rest), dim=2)
+        return plan.recon.clone()
+
     def _ids_out(self, plan: Plan):
         x = plan.latent
         ids = plan.ids.reshape(x.B, x.T, x.H, x.W, plan.pm.ncb).clone()
@@ -350,7 +359,7 @@ class VideoTokenizer(nn.Module):
         assert video_contains_first_frame, 'headless videos are out of scope'
         video = self._check_video(video)
         plan, key = self._plan(video.shape[0], video.shape[2])
-        plan.video_in.copy_(video)
+        self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
         if not quantize:
             self._run(plan, key, 'enc', [plan.enc_steps])
@@ -372,7 +381,7 @@ class VideoTokenizer(nn.Module):
         assert (C, Tl, Hl, Wl) == (q.C, q.T, q.H, q.W)
         q.t[: q.rows * q.C].reshape(B, Tl, Hl, Wl, C).copy_(quantized.permute(0, 2, 3, 4, 1))
         self._run(plan, key, 'dec', [plan.dec_steps])
-        return plan.recon.clone()
+        return self._recon_out(plan)
 
     @torch.no_grad()
     def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):
@@ -390,7 +399,7 @@ class VideoTokenizer(nn.Module):
         plan.ids_in.copy_(codes.reshape(-1, ncb))
         self._set_cond(plan, cond, B)
         self._run(plan, key, 'codes+dec', [plan.codes_steps, plan.dec_steps])
-        return plan.recon.clone()
+        return self._recon_out(plan)
 
     @torch.no_grad()
     def tokenize(self, video, cond=None):
@@ -414,20 +423,22 @@ class VideoTokenizer(nn.Module):
             if return_loss:
                 return self._forward_loss(video, cond)
             plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
-            plan.video_in.copy_(video)
+            self._set_video(plan, video)
             self._set_cond(plan, cond, video.shape[0])
             if return_codes and not return_recon:
                 self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
                 codes = self._ids_out(plan)
                 return (codes, plan.prequant.clone()) if return_prequant else codes
             self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
-            recon = plan.recon.clone()
+            recon = self._recon_out(plan)
             if video_or_images.ndim == 4:
                 pass   # the reference also returns a 5-D (T = 1) reconstruction for image input
             if return_codes:
                 codes = self._ids_out(plan)
                 return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
             if return_recon_loss_only:
+                if plan.sep:
+                    raise NotImplementedError('return_recon_loss_only with separate_first_frame_encoding is not built')
                 plan.run(plan.loss_steps[:1])
                 return plan.sq_sum[0] / plan.video_in.numel(), recon
             return recon
@@ -439,9 +450,11 @@ class VideoTokenizer(nn.Module):
         over the default process group when one is initialised (the third-party code all-reduces the mean code distribution; here
         every token-sum travels, so each rank reports the GLOBAL-batch auxiliary loss).  The reconstruction loss stays per
         rank, as in the reference."""
+        if self.separate_first_frame_encoding:
+            raise NotImplementedError('forward(return_loss=True) with separate_first_frame_encoding is not built (the loss kernels read one recon buffer)')
         train = self.training and not self.use_fsq
         plan, key = self._plan(video.shape[0], video.shape[2], train=train)
-        plan.video_in.copy_(video)
+        self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
         self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
         recon_loss = plan.sq_sum[0] / plan.video_in.numel()

@@ -347,6 +347,18 @@ class CpuOps:
         step.what = 'se_pool_fc1'
         return step
 
+    def copy_frames(self, src, src_T, src_t0, dst, dst_T, dst_t0, nT, B, frame_bytes):
+        def step(stream):
+            fe = frame_bytes // dst.element_size()
+            d = dst.reshape(-1)[: B * dst_T * fe].reshape(B, dst_T, fe)
+            if src is None:
+                d[:, dst_t0: dst_t0 + nT] = 0
+            else:
+                d[:, dst_t0: dst_t0 + nT] = src.reshape(-1)[: B * src_T * fe].reshape(B, src_T, fe)[:, src_t0: src_t0 + nT]
+        step.outs = [dst]
+        step.what = 'copy_frames'
+        return step
+
     def cond_linear(self, x, w, bias, out, B, I, O, mode, eps=1e-8):
         def step(stream):
             xv = x.reshape(-1)[: B * I].reshape(B, I).double()

@@ -334,7 +334,7 @@ class OracleTokenizer:
     def __init__(self, state_dict, *, image_size, layers, codebook_size=None, init_dim=64, max_dim=float('inf'),
                  channels=3, num_codebooks=1, use_fsq=False, fsq_levels=None, attn_dim_head=32, attn_heads=8,
                  linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10., dim_cond=None,
-                 dtype=torch.float32, **_ignored):
+                 separate_first_frame_encoding=False, dtype=torch.float32, **_ignored):
         self.p = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone())
                   for k, v in state_dict.items() if not k.startswith('discr.')}
         self.dtype = dtype
@@ -351,6 +351,7 @@ class OracleTokenizer:
         self.time_downsample_factor = 2 ** sum(s['kind'] == 'compress_time' for s in self.stages)
         self.time_padding = self.time_downsample_factor - 1
         self.fmap_size = image_size // (2 ** sum(s['kind'] == 'compress_space' for s in self.stages))
+        self.separate_first_frame = bool(separate_first_frame_encoding)
         self.dim_cond = dim_cond
         self.has_cond = any(st['kind'].startswith('cond_') for st in self.stages)
         self.taps = None            # optional dict name -> tensor for layer-wise debugging
@@ -404,8 +405,17 @@ class OracleTokenizer:
         """M:1522-1576 (video_contains_first_frame=True, no separate first frame).
         NB the trailing LayerNorm of encoder_layers is never executed (zip truncation, M:1565)."""
         x = video.to(self.dtype)
-        x = F.pad(x, (0, 0, 0, 0, self.time_padding, 0))                        # M:1537
-        x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
+        if self.separate_first_frame:
+            # M:1553-1561: first frame through its own SameConv2d, the REMAINING frames through conv_in (whose causal zero
+            # padding starts right before frame 1 — it never sees the first frame), then time_padding zero frames in front
+            w2 = self.p['conv_in_first_frame.weight']
+            ff = F.conv2d(x[:, :, 0], w2, self.p['conv_in_first_frame.bias'], padding=(w2.shape[-2] // 2, w2.shape[-1] // 2))
+            rest = causal_conv3d(x[:, :, 1:], self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias'])
+            x = torch.cat((ff.unsqueeze(2), rest), dim=2)
+            x = self._tap('conv_in', F.pad(x, (0, 0, 0, 0, self.time_padding, 0)))
+        else:
+            x = F.pad(x, (0, 0, 0, 0, self.time_padding, 0))                    # M:1537
+            x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
         ce = self._cond_in(cond, 'encoder_cond_in')
         for i, st in enumerate(self.stages):
             x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True, cond=ce))
@@ -431,6 +441,12 @@ class OracleTokenizer:
         cd = self._cond_in(cond, 'decoder_cond_in')
         for j, st in enumerate(reversed(self.stages)):
             x = self._tap(f'dec{j}', self._stage(x, st, f'decoder_layers.{j}', False, cond=cd))
+        if self.separate_first_frame:                                            # M:1633-1639
+            tp = self.time_padding
+            w2 = self.p['conv_out_first_frame.weight']
+            outff = F.conv2d(x[:, :, tp], w2, self.p['conv_out_first_frame.bias'], padding=(w2.shape[-2] // 2, w2.shape[-1] // 2))
+            out = causal_conv3d(x[:, :, tp + 1:], self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
+            return torch.cat((outff.unsqueeze(2), out), dim=2)
         x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
         return x[:, :, self.time_padding:]                                       # M:1646-1647
 

@@ -386,3 +386,21 @@ def test_c_packer_known_bytes():
     assert img[0, 1, :8].view(torch.bfloat16).float().tolist() == [9., 10., 11., 12., 13., 14., 15., 16.]
     assert int(img[0, 0, 0]) == 0x3F80 and int(img[0, 1, 0]) == 0x4110       # bf16(1.0), bf16(9.0)
     assert not img[0, 2:].any() and not img[0, :2, 8:].any()
+
+
+def test_separate_first_frame_encoding_matches_oracle():
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=4, randomize_se=True)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    v = torch.randn(2, 3, 9, 16, 16, generator=torch.Generator().manual_seed(1))
+    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    assert torch.equal(codes, ocodes) and (recon - orecon).abs().max().item() <= 5e-6
+    assert (tok.decode_from_code_indices(ocodes) - orecon).abs().max().item() <= 5e-6
+    q, _, _ = tok.encode(v, quantize=True)
+    assert (tok.decode(q) - orecon).abs().max().item() <= 5e-6
+    assert 'conv_in_first_frame.weight' in tok.state_dict() and tok.state_dict()['conv_out_first_frame.weight'].shape == (3, 16, 3, 3)
+    with pytest.raises(AssertionError):
+        tok(torch.randn(2, 3, 16, 16), return_codes=True)           # a single frame: the reference fails too (conv_in on an empty clip)

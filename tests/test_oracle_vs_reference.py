@@ -137,3 +137,25 @@ def test_reference_cannot_run_conditioned_attention():
         sa(torch.randn(2, 32, 1, 4, 4), cond=cond)
     with pytest.raises(TypeError):
         make_reference_tokenizer(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8, layers=('residual', 'cond_linear_attend_space'))
+
+
+def test_separate_first_frame_encoding_matches_reference():
+    """conv_in_first_frame / conv_out_first_frame (SameConv2d, M:1113-1120, 1553-1561, 1633-1639) end to end through the reference."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=4, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    rsd = {k: v for k, v in ref.state_dict().items() if not k.startswith('discr.')}
+    assert set(rsd) == set(sd) and all(tuple(rsd[k].shape) == tuple(sd[k].shape) for k in sd)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 9, 16, 16, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes)
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
+    with pytest.raises(RuntimeError):                                # the reference cannot take a single frame in this mode
+        ref(torch.randn(1, 3, 1, 16, 16), return_codes=True)

@@ -383,3 +383,25 @@ def test_conditioned_layers_fp32_vs_oracle(name):
     assert (other - recon).abs().max().item() > 1e-3
     with pytest.raises(AssertionError):
         tok(v.cuda(), return_codes=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_separate_first_frame_encoding(dtype):
+    """first frame through its own 2-D convs (reference M:1553-1561, 1633-1639); lockstep + fp32 parity vs the oracle."""
+    kw = dict(image_size=32, init_dim=64, max_dim=128, codebook_size=256, separate_first_frame_encoding=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=41, randomize_se=True)
+    v = torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(42))
+    run_lockstep(cfg, sd, v, dtype)
+    if dtype == torch.float32:
+        orc = OracleTokenizer(sd, **cfg)
+        orc.taps = {}
+        ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+        tok = hip_tokenizer(kw, sd, torch.float32)
+        for rep in range(3):
+            codes, recon = tok(v.cuda(), return_codes=True, return_recon=True)
+            margin_check(codes, ocodes, orc.taps['prequant'], 1e-4, 0.005)
+            if torch.equal(codes.cpu(), ocodes):
+                assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
+        assert (tok.decode_from_code_indices(ocodes.cuda()).cpu() - orecon).abs().max().item() <= 5e-4
