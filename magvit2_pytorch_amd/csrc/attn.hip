@@ -339,38 +339,25 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
-    // four tokens of loads in flight: the loop used to be a chain of ~40 dependent global-load latencies per block
-    constexpr int U = 4, NC = 8 / E::kVec;
-    for (int t = t0; t < t1; t += U) {
-        i32x4 kr[U][NC], vr[U][NC];
+    for (int t = t0; t < t1; ++t) {
+        const int64_t row = ((int64_t)f * n + t) * ld;
+        float k[8], v[9];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tu = min(t + u, t1 - 1);
-            const int64_t row = ((int64_t)f * n + tu) * ld;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                kr[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
-                vr[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
-            }
+        for (int c = 0; c < 8 / E::kVec; ++c) {
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
         }
+        v[8] = 1.f;
+        float ki = k[0];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (t + u >= t1) break;
-            float k[8], v[9];
+        for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kr[u][c], k + c * E::kVec); Chunk<E>::unpack(vr[u][c], v + c * E::kVec); }
-            v[8] = 1.f;
-            float ki = k[0];
+        for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
 #pragma unroll
-            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+        for (int jj = 0; jj < 8; ++jj) {
+            const float ph = (ki * k[jj]) * r2;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float ph = (ki * k[jj]) * r2;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
-            }
+            for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
         }
     }
     float* dst = part + (((int64_t)f * nchunk + j) * heads + h) * TAY_S;
@@ -392,7 +379,15 @@ __global__ __launch_bounds__(256) void taylor_reduce_kernel(const float* __restr
     const int f = fh / heads, h = fh % heads;
     for (int e = threadIdx.x; e < TAY_S; e += 256) {
         float a = 0.f;
-        for (int j = 0; j < nchunk; ++j) a += part[(((int64_t)f * nchunk + j) * heads + h) * TAY_S + e];
+        int j = 0;
+        for (; j + 8 <= nchunk; j += 8) {                            // eight independent loads in flight, summed in chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(((int64_t)f * nchunk + j + u) * heads + h) * TAY_S + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; j < nchunk; ++j) a += part[(((int64_t)f * nchunk + j) * heads + h) * TAY_S + e];
         kvsum[(int64_t)fh * TAY_S + e] = a;
     }
 }

@@ -276,7 +276,15 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
         const int c = tid % C, js = tid / C;
         if (js < JS) {
             float a = 0.f;
-            for (int j = js; j < nchunk; j += JS) a += pf[(int64_t)j * (C + 2) + 2 + c] * wj[j];
+            int j = js;
+            for (; j + 7 * JS < nchunk; j += 8 * JS) {             // eight loads in flight (the plain loop was a chain of L2 latencies)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = pf[(int64_t)(j + u * JS) * (C + 2) + 2 + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u] * wj[j + u * JS];
+            }
+            for (; j < nchunk; j += JS) a += pf[(int64_t)j * (C + 2) + 2 + c] * wj[j];
             slab[js * C + c] = a;
         }
         __syncthreads();
@@ -302,7 +310,13 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) { a0 += w[u] * pooled[c + u]; a1 += w[u + 1] * pooled[c + u + 1]; }
             }
-            for (; c < c1; ++c) a0 += w1t[(int64_t)c * hidden + k] * pooled[c];
+            if (c < c1) {                                            // tail (< 16): still one batch of independent loads
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = (c + u < c1) ? w1t[(int64_t)(c + u) * hidden + k] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a0 += (c + u < c1) ? w[u] * pooled[c + u] : 0.f;
+            }
             slab[cs * hidden + k] = a0 + a1;
         }
         __syncthreads();
@@ -328,7 +342,13 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) { a0 += w[u] * hid[k + u]; a1 += w[u + 1] * hid[k + u + 1]; }
             }
-            for (; k < k1; ++k) a0 += w2t[(int64_t)k * C + c] * hid[k];
+            if (k < k1) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = (k + u < k1) ? w2t[(int64_t)(k + u) * C + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a0 += (k + u < k1) ? w[u] * hid[k + u] : 0.f;
+            }
             slab[ks * C + c] = a0 + a1;
         }
         __syncthreads();
@@ -438,6 +458,7 @@ __global__ __launch_bounds__(1024) void se_rec_fc1_kernel(const float* __restric
     float* pooled = wr + R;             // C
     float* slab = pooled + C;           // 1024
     const float* pf = part + (int64_t)f * nchunk * (C + 2);
+#pragma unroll 4
     for (int i = tid; i < R * (C + 2); i += 1024) sm[i] = pf[i];
     __syncthreads();
     float M = -INFINITY;

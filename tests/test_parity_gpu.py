@@ -76,6 +76,9 @@ def run_lockstep(cfg, sd, v, dtype, cond=None):
     ph = Plan(PackedModel(cfg, sd, dtype, hops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
     pc = Plan(PackedModel(cfg, sd, dtype, cops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
     ph.video_in.copy_(v); pc.video_in.copy_(v)
+    if ph.sep:
+        for pl in (ph, pc):
+            pl.video_first.copy_(v[:, :, :1]); pl.video_rest.copy_(v[:, :, 1:])
     if cond is not None:
         ph.cond_in.copy_(cond); pc.cond_in.copy_(cond)
     tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
