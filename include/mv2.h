@@ -44,7 +44,7 @@ enum {
 };
 
 /* activation applied in the conv epilogue */
-enum { MV2_ACT_NONE = 0, MV2_ACT_ELU = 1, MV2_ACT_SILU = 2, MV2_ACT_GEGLU = 3 };
+enum { MV2_ACT_NONE = 0, MV2_ACT_ELU = 1, MV2_ACT_SILU = 2, MV2_ACT_GEGLU = 3, MV2_ACT_LRELU = 4 /* leaky_relu(0.1), discriminator M:117 */ };
 /* store mode of the conv epilogue */
 enum {
     MV2_STORE_ROWS = 0,      /* out[row][n]                                   dense NDHWC          */
@@ -302,6 +302,8 @@ int mv2_lfq_losses(const float* sums, double n_tokens, int cb_dim, int num_codeb
                    float entropy_loss_weight, float commitment_loss_weight, float* losses, void* stream);
 size_t mv2_sq_diff_workspace_bytes(int64_t n);
 int mv2_sq_diff_sum(const float* a, const float* b, int64_t n, float* sum, void* workspace, size_t workspace_bytes, void* stream);
+/* hinge discriminator loss (reference M:120-121): out[0] = mean(relu(1 + fake) + relu(1 - real)) over n fp32 logits. */
+int mv2_hinge_discr_loss(const float* fake, const float* real, int n, float* out, void* stream);
 int mv2_lfq_codes(int dtype, const int64_t* ids, const float* w_out_t, const float* b_out, void* out,
                   int64_t rows, int C, int cb_dim, int num_codebooks, float scale, void* stream);
 int mv2_fsq(int dtype, const void* x, const float* w_in, const float* b_in, const float* w_out_t,

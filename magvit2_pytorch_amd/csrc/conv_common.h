@@ -82,6 +82,9 @@ __device__ __forceinline__ void epi_store4(const ConvParams& p, int64_t m, int n
     } else if (d.act == MV2_ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = Act<E>::silu(v[j]);
+    } else if (d.act == MV2_ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.1f * v[j];
     }
     if (d.store == MV2_STORE_ROWS) {
         int64_t o = m * d.out_c + n;
@@ -233,6 +236,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
                         float x = acc[a][b][4 * g + j] * rs + bv[j];
                         if (d.act == MV2_ACT_ELU) x = Act<E>::elu(x);
                         else if (d.act == MV2_ACT_SILU) x = Act<E>::silu(x);
+                        else if (d.act == MV2_ACT_LRELU) x = x > 0.f ? x : 0.1f * x;
                         v[j] = x;
                     }
                     if (wide) lds_put4<F32>(rowp + col * 4, v);

@@ -410,3 +410,20 @@ extern "C" int mv2_sq_diff_sum(const float* a, const float* b, int64_t n, float*
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// ------------------------------------------------------------------------------- hinge discriminator loss (reference M:120-121)
+// out[0] = mean(relu(1 + fake) + relu(1 - real)) over n logits; one workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void hinge_discr_kernel(const float* __restrict__ fake, const float* __restrict__ real, int n, float* out) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += fmaxf(1.f + fake[i], 0.f) + fmaxf(1.f - real[i], 0.f);
+    const float t = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+
+extern "C" int mv2_hinge_discr_loss(const float* fake, const float* real, int n, float* out, void* stream) {
+    if (!fake || !real || !out || n <= 0) return MV2_EINVAL;
+    hipLaunchKernelGGL(hinge_discr_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fake, real, n, out);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

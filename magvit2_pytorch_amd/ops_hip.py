@@ -70,6 +70,7 @@ _SIGS = {
     'mv2_lfq_losses': (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'mv2_sq_diff_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'mv2_sq_diff_sum': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_hinge_discr_loss': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'mv2_lfq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'mv2_fsq': (C.c_int, [C.c_int] + [C.c_void_p] * 13 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_fsq_codes': (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -305,6 +306,10 @@ class HipOps:
         fn = self.lib.mv2_sq_diff_sum
         args = (_ptr(a), _ptr(b), n, _ptr(out), _ptr(ws), ws.numel() * ws.element_size())
         return _mk(fn, args, 'mv2_sq_diff_sum', (a, b, out, ws), [out])
+
+    def hinge_discr_loss(self, fake, real, n, out):
+        fn, args = self.lib.mv2_hinge_discr_loss, (_ptr(fake), _ptr(real), n, _ptr(out))
+        return _mk(fn, args, 'mv2_hinge_discr_loss', (fake, real, out), [out])
 
     def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):
         fn, args = self.lib.mv2_lfq_codes, (dt, _ptr(ids), _ptr(w_out), _ptr(b_out), _ptr(out), rows, Cc, cb_dim, ncb, float(scale))

@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import torch
 
 MV2_BF16, MV2_F32 = 0, 1
-ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU, ACT_LRELU = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32 = 0, 1, 2
 FILLER_SEL = 0x80000000
 

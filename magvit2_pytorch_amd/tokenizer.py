@@ -34,6 +34,7 @@ __version__ = '0.1.0'
 LossBreakdown = namedtuple('LossBreakdown', ['recon_loss', 'lfq_aux_loss', 'quantizer_loss_breakdown', 'perceptual_loss',
                                              'adversarial_gen_loss', 'adaptive_adversarial_weight', 'multiscale_gen_losses',
                                              'multiscale_gen_adaptive_weights'])
+DiscrLossBreakdown = namedtuple('DiscrLossBreakdown', ['discr_loss', 'multiscale_discr_losses', 'gradient_penalty'])      # reference :1039-1043
 QuantizerLossBreakdown = namedtuple('QuantizerLossBreakdown', ['per_sample_entropy', 'batch_entropy', 'commitment'])
 
 
@@ -142,6 +143,10 @@ class VideoTokenizer(nn.Module):
         self.lfq_entropy_loss_weight = float(lfq_entropy_loss_weight)
         self.lfq_commitment_loss_weight = float(lfq_commitment_loss_weight)
         self.lfq_diversity_gamma = float(lfq_diversity_gamma)
+        self.adversarial_loss_weight = float(adversarial_loss_weight)
+        self.has_gan = self.use_gan and self.adversarial_loss_weight > 0.                       # reference :1427
+        if len(multiscale_discrs) > 0:
+            raise NotImplementedError('multiscale discriminators are outside this build')
         self._validate_widths(channels, stages=S.parse_layers(self.cfg['layers'], init_dim, max_dim))
         self.channels = channels
         self.image_size = image_size
@@ -164,6 +169,11 @@ class VideoTokenizer(nn.Module):
             _register(self, ps.name, S.init_tensor(ps, gen), ps.buffer)
             self._param_names.append(ps.name)
         self.register_buffer('zero', torch.tensor(0.), persistent=False)
+        # image discriminator (reference :1413-1422: dim = the encoder's final width); parameters under `discr.*` as in the reference
+        from .discriminator import Discriminator
+        dk = dict(discr_kwargs) if _exists(discr_kwargs) else dict(dim=stages[-1].dim_out if stages else init_dim, image_size=image_size,
+                                                                  channels=channels, max_dim=512)
+        self.discr = Discriminator(**dk, seed=(seed + 1) if seed is not None else None) if self.use_gan else None
 
         self.compute_dtype: Optional[torch.dtype] = None      # None = infer (see module docstring)
         self.use_hip_graph = True
@@ -198,9 +208,15 @@ class VideoTokenizer(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """Accepts a reference state_dict unchanged: discriminator / VGG entries are ignored."""
-        sd = {k: v for k, v in state_dict.items() if not (k.startswith('discr.') or k.startswith('vgg.') or k.startswith('multiscale_discrs.'))}
+        has_discr = self.discr is not None and any(k.startswith('discr.') for k in state_dict)
+        sd = {k: v for k, v in state_dict.items()
+              if not ((k.startswith('discr.') and not has_discr) or k.startswith('vgg.') or k.startswith('multiscale_discrs.'))}
+        if self.discr is not None and not has_discr:          # tokenizer-only checkpoint: the discriminator keeps its weights
+            sd.update({'discr.' + k: v for k, v in self.discr.state_dict().items()})
         out = super().load_state_dict(sd, strict=strict, **kw)
         self.refresh_weights()
+        if self.discr is not None:
+            self.discr.refresh_weights()
         return out
 
     def refresh_weights(self):
@@ -412,7 +428,10 @@ class VideoTokenizer(nn.Module):
                 return_prequant=False):
         assert (return_loss + return_codes + return_discr_loss) <= 1              # reference :1674
         if return_discr_loss:
-            raise NotImplementedError('the discriminator loss is outside the hot-path scope of this build (SURVEY.md §8f)')
+            assert self.has_gan and _exists(self.discr)                               # reference :1731-1732
+            if apply_gradient_penalty:
+                raise NotImplementedError('the gradient penalty differentiates the discriminator (reference :102-116); this build has '
+                                          'forward values only: pass apply_gradient_penalty=False')
         if return_loss and (self.use_gan or self.perceptual_loss_weight > 0.):
             raise NotImplementedError('forward(return_loss=True) covers the reconstruction + quantizer auxiliary losses only: '
                                       'construct with use_gan=False, perceptual_loss_weight=0. (VGG / discriminators are outside '
@@ -422,6 +441,8 @@ class VideoTokenizer(nn.Module):
         with torch.no_grad():
             if return_loss:
                 return self._forward_loss(video, cond)
+            if return_discr_loss:
+                return self._forward_discr_loss(video, cond)
             plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
             self._set_video(plan, video)
             self._set_cond(plan, cond, video.shape[0])
@@ -442,6 +463,29 @@ class VideoTokenizer(nn.Module):
                 plan.run(plan.loss_steps[:1])
                 return plan.sq_sum[0] / plan.video_in.numel(), recon
             return recon
+
+    def _forward_discr_loss(self, video, cond=None):
+        """forward(return_discr_loss=True, apply_gradient_penalty=False) (reference M:1730-1782): a random frame per sample of the
+        clip and of its reconstruction through the image discriminator, hinge loss of the two logit vectors."""
+        plan, key = self._plan(video.shape[0], video.shape[2])
+        self._set_video(plan, video)
+        self._set_cond(plan, cond, video.shape[0])
+        self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
+        recon = self._recon_out(plan)
+        batch, frames = video.shape[0], video.shape[2]
+        frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices.to(video.device)      # CPU generator, as the reference (:1736)
+        bi = torch.arange(batch, device=video.device)
+        real = video[bi, :, frame_indices[:, 0]].float()
+        fake = recon[bi, :, frame_indices[:, 0]]
+        if self.discr._ops is None and getattr(plan.ops, 'name', '') != 'hip':
+            self.discr._set_backend(plan.ops)                     # test hook: the emulation backend serves both modules
+        self.discr.compute_dtype = plan.dtype
+        real_logits, fake_logits = self.discr(real), self.discr(fake)
+        out = plan.ops.empty((1,), torch.float32)
+        plan.run([plan.ops.hinge_discr_loss(fake_logits, real_logits, batch, out)])
+        discr_loss = out[0].clone()
+        zero = torch.zeros((), device=discr_loss.device)
+        return discr_loss, DiscrLossBreakdown(discr_loss, [zero], zero)
 
     def _forward_loss(self, video, cond=None):
         """forward(return_loss=True) (reference M:1705-1722, 1785-1817 with use_gan=False, no perceptual loss): forward values only

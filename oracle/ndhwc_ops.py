@@ -17,7 +17,7 @@ import math
 
 import torch
 
-ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU, ACT_LRELU = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32 = 0, 1, 2
 
 
@@ -114,6 +114,8 @@ class CpuOps:
                 D = torch.nn.functional.elu(D)
             elif d['act'] == ACT_SILU:
                 D = torch.nn.functional.silu(D)
+            elif d['act'] == ACT_LRELU:
+                D = torch.nn.functional.leaky_relu(D, 0.1)
             if d['act'] == ACT_GEGLU:
                 hp = co // 2
                 Dv = D[:, :co].reshape(M, co // 64, 2, 32)
@@ -547,6 +549,14 @@ class CpuOps:
             out[0] = float(((a.reshape(-1)[:n].double() - b.reshape(-1)[:n].double()) ** 2).sum())
         step.outs = [out]
         step.what = 'sq_diff_sum'
+        return step
+
+    def hinge_discr_loss(self, fake, real, n, out):
+        def step(stream):
+            f_, r_ = fake.reshape(-1)[:n].double(), real.reshape(-1)[:n].double()
+            out[0] = float((torch.relu(1 + f_) + torch.relu(1 - r_)).mean())
+        step.outs = [out]
+        step.what = 'hinge_discr_loss'
         return step
 
     def lfq_codes(self, dt, ids, w_out, b_out, out, rows, Cc, cb_dim, ncb, scale):

@@ -502,4 +502,60 @@ class OracleTokenizer:
         total = recon_loss + aux * quantizer_aux_loss_weight
         return total, dict(recon_loss=recon_loss, aux=aux, per_sample_entropy=ps, batch_entropy=bt, commitment=cm)
 
+    def forward_discr_loss(self, video, discr_params, *, dim, channels=3, max_dim=512, cond=None):
+        """M:1730-1782 with apply_gradient_penalty=False and no multiscale discriminators: one random frame per sample
+        (torch.randn((batch, frames)).topk(1) on the CPU default generator — seed it before the call to compare), real and
+        reconstructed frame through the image discriminator, hinge loss.  discr_params: the `discr.*` entries."""
+        if video.ndim == 4:
+            video = video.unsqueeze(2)
+        with torch.no_grad():
+            recon = self.forward(video, cond=cond, return_recon=True)
+            batch, frames = video.shape[0], video.shape[2]
+            frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices
+            bi = torch.arange(batch)
+            real, fake = video[bi, :, frame_indices[:, 0]], recon[bi, :, frame_indices[:, 0]]
+            kw = dict(dim=dim, image_size=self.image_size, channels=channels, max_dim=max_dim)
+            real_logits = discriminator_forward(real, discr_params, 'discr.', **kw)
+            fake_logits = discriminator_forward(fake, discr_params, 'discr.', **kw)
+        return hinge_discr_loss(fake_logits, real_logits), real_logits, fake_logits
+
     __call__ = forward
+
+
+# ----------------------------------------------------------------------------- discriminator (SURVEY §8 f4)
+def discriminator_dims(dim, image_size, channels=3, max_dim=512):
+    """Discriminator.__init__ M:605-630: (in, out) channels per block; the last block does not downsample."""
+    num_layers = int(math.log2(image_size) - 2)
+    dims = [channels] + [min((dim * 4) * (2 ** i), max_dim) for i in range(num_layers + 1)]
+    return list(zip(dims[:-1], dims[1:]))
+
+
+def discriminator_forward(x, p, pre, *, dim, image_size, channels=3, max_dim=512, linear_attn_heads=16, linear_attn_dim_head=8):
+    """Discriminator.forward M:670-676 (antialiased_downsample=False, the default): per block DiscriminatorBlock M:575-588
+    (1x1 stride-2 residual conv; conv3x3 + leaky_relu(0.1) twice; space-to-depth + 1x1 conv; (x + res) / sqrt 2), then
+    Residual(LinearSpaceAttention) + Residual(FeedForward(images=True)); to_logits: conv3x3, leaky_relu, flatten, Linear -> (B,)."""
+    pairs = discriminator_dims(dim, image_size, channels, max_dim)
+    for i, (cin, cout) in enumerate(pairs):
+        b = f'{pre}blocks.{i}.0.'
+        last = i == len(pairs) - 1
+        res = F.conv2d(x, p[b + 'conv_res.weight'], p[b + 'conv_res.bias'], stride=1 if last else 2)
+        h = F.leaky_relu(F.conv2d(x, p[b + 'net.0.weight'], p[b + 'net.0.bias'], padding=1), 0.1)
+        h = F.leaky_relu(F.conv2d(h, p[b + 'net.2.weight'], p[b + 'net.2.bias'], padding=1), 0.1)
+        if not last:
+            B, C, H, W = h.shape
+            h = h.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, C * 4, H // 2, W // 2)   # 'b c (h p1) (w p2) -> b (c p1 p2) h w'
+            h = F.conv2d(h, p[b + 'downsample.1.weight'], p[b + 'downsample.1.bias'])
+        x = (h + res) * (2 ** -0.5)
+        a = f'{pre}blocks.{i}.1.'
+        x5 = x.unsqueeze(2)
+        x5 = linear_space_attention(x5, p, a + '0.fn.', linear_attn_heads, linear_attn_dim_head) + x5
+        pf = {k: (v.unsqueeze(-1) if (k.startswith(a + '1.fn.') and v.ndim >= 3) else v) for k, v in p.items() if k.startswith(a + '1.fn.')}
+        x5 = feed_forward(x5, pf, a + '1.fn.') + x5                    # images=True: Conv2d / (dim, 1, 1) gamma, same arithmetic
+        x = x5.squeeze(2)
+    h = F.leaky_relu(F.conv2d(x, p[pre + 'to_logits.0.weight'], p[pre + 'to_logits.0.bias'], padding=1), 0.1)
+    return h.flatten(1) @ p[pre + 'to_logits.3.weight'].t().squeeze(-1) + p[pre + 'to_logits.3.bias']
+
+
+def hinge_discr_loss(fake, real):
+    """M:120-121."""
+    return (F.relu(1 + fake) + F.relu(1 - real)).mean()

@@ -114,7 +114,9 @@ def test_state_dict_keys_and_round_trip(tmp_path):
     kw = dict(image_size=32, init_dim=8, max_dim=32, codebook_size=256, layers=README_LAYERS)
     tok = VideoTokenizer(**kw, seed=3)
     names = {p.name for p in param_specs(make_cfg(**kw))}
-    assert set(tok.state_dict().keys()) == names
+    from magvit2_pytorch_amd.discriminator import discriminator_param_specs
+    dnames = {'discr.' + p.name for p in discriminator_param_specs(dim=32, image_size=32, channels=3, max_dim=512)}   # reference :1413-1422
+    assert set(tok.state_dict().keys()) == names | dnames
     assert 'encoder_layers.14.1.weight' in names            # the never-executed LayerNorm keeps its keys (reference :1322-1326)
     assert 'decoder_layers.0.0.fn.fn.to_qkv.0.weight' in names and 'encoder_layers.5.0.fn.attn.to_kv.0.weight' in names
     path = tmp_path / 'tok.pt'
@@ -122,10 +124,15 @@ def test_state_dict_keys_and_round_trip(tmp_path):
     tok2 = VideoTokenizer.init_and_load_from(str(path))
     for k, v in tok.state_dict().items():
         assert torch.equal(v, tok2.state_dict()[k])
-    # reference checkpoints carry discriminator weights: ignored on load
-    sd = dict(tok.state_dict())
-    sd['discr.blocks.0.net.0.weight'] = torch.zeros(3)
-    tok2.load_state_dict(sd)
+    # a tokenizer-only state_dict loads too (the discriminator keeps its weights) ...
+    before = tok2.state_dict()['discr.to_logits.3.weight'].clone()
+    tok2.load_state_dict({k: v for k, v in tok.state_dict().items() if not k.startswith('discr.')})
+    assert torch.equal(tok2.state_dict()['discr.to_logits.3.weight'], before)
+    # ... and a tokenizer built without the GAN ignores a checkpoint's discriminator / VGG entries
+    tok3 = VideoTokenizer(**kw, use_gan=False, seed=4)
+    assert set(tok3.state_dict().keys()) == names
+    tok3.load_state_dict(dict(tok.state_dict(), **{'vgg.features.0.weight': torch.zeros(3)}))
+    assert torch.equal(tok3.state_dict()['conv_in.conv.weight'], tok.state_dict()['conv_in.conv.weight'])
 
 
 def test_ctor_and_call_asserts():
@@ -404,3 +411,36 @@ def test_separate_first_frame_encoding_matches_oracle():
     assert 'conv_in_first_frame.weight' in tok.state_dict() and tok.state_dict()['conv_out_first_frame.weight'].shape == (3, 16, 3, 3)
     with pytest.raises(AssertionError):
         tok(torch.randn(2, 3, 16, 16), return_codes=True)           # a single frame: the reference fails too (conv_in on an empty clip)
+
+
+# ------------------------------------------------------------------------------- discriminator: lowering on the CPU emulation
+def test_discriminator_lowering_matches_oracle():
+    from magvit2_pytorch_amd.discriminator import Discriminator
+    from oracle.restate import discriminator_forward
+    kw = dict(dim=8, image_size=16, channels=3, max_dim=64)
+    d = Discriminator(**kw, seed=2)
+    d._set_backend(CpuOps())
+    d.compute_dtype = torch.float32
+    x = torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    want = discriminator_forward(x, {'discr.' + k: v for k, v in d.state_dict().items()}, 'discr.', **kw)
+    got = d(x)
+    assert got.shape == (3,) and got.dtype == torch.float32 and (got - want).abs().max().item() <= 2e-6
+    with pytest.raises(NotImplementedError):
+        Discriminator(**kw, antialiased_downsample=True)
+
+
+def test_forward_return_discr_loss_matches_oracle():
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    dsd = {k: v.clone() for k, v in tok.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(77)
+    total, br = tok(v, return_discr_loss=True, apply_gradient_penalty=False)
+    torch.manual_seed(77)
+    want, _, _ = OracleTokenizer(sd, **cfg).forward_discr_loss(v, dsd, dim=16, max_dim=512)
+    assert br._fields == ('discr_loss', 'multiscale_discr_losses', 'gradient_penalty')
+    assert abs(float(total) - float(want)) <= 2e-6 and float(br.gradient_penalty) == 0.
+    with pytest.raises(NotImplementedError):
+        tok(v, return_discr_loss=True)                               # gradient penalty (the reference's default) needs autograd

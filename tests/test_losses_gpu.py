@@ -144,3 +144,54 @@ def test_forward_return_loss_bf16_drift():
     assert abs(float(qb.per_sample_entropy) - float(d['per_sample_entropy'])) <= 6.3e-3
     assert abs(float(qb.batch_entropy) - float(d['batch_entropy'])) <= 3.9e-3
     assert abs(float(qb.commitment) - float(d['commitment'])) <= 2e-4
+
+
+# ------------------------------------------------------------------------------- discriminator
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize('kw', [dict(dim=8, image_size=16, channels=3, max_dim=64), dict(dim=64, image_size=32, channels=3, max_dim=512)])
+def test_discriminator_forward_vs_oracle(kw, dtype, tol):
+    """Discriminator.forward (reference M:670-676) on the HIP kernels vs the CPU restatement (pinned against the reference module in
+    tests/test_oracle_vs_reference.py).  fp32 mode: exact-fp32 MFMA, summation order only; bf16 mode: bf16 storage drift on O(0.05..1) logits."""
+    from magvit2_pytorch_amd.discriminator import Discriminator
+    from oracle.restate import discriminator_forward
+    d = Discriminator(**kw, seed=2)
+    sd = {k: v.clone() for k, v in d.state_dict().items()}
+    d = d.cuda()
+    d.compute_dtype = dtype
+    x = torch.randn(3, 3, kw['image_size'], kw['image_size'], generator=torch.Generator().manual_seed(3))
+    want = discriminator_forward(x, {'discr.' + k: v for k, v in sd.items()}, 'discr.', **kw)
+    got = d(x.cuda()).cpu()
+    assert got.shape == (3,) and torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= tol * max(1., want.abs().max().item()), (got, want)
+    assert torch.equal(d(x.cuda()).cpu(), got)                        # second call: cached plan, same result
+
+
+def test_forward_return_discr_loss_fp32_matches_oracle():
+    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=21, randomize_se=True)
+    tok = VideoTokenizer(**kw, seed=0)
+    tok.load_state_dict(sd)
+    dsd = {k: v.clone() for k, v in tok.state_dict().items() if k.startswith('discr.')}
+    tok = tok.cuda()
+    tok.compute_dtype = torch.float32
+    v = torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(22))
+    torch.manual_seed(5)
+    total, br = tok(v.cuda(), return_discr_loss=True, apply_gradient_penalty=False)
+    torch.manual_seed(5)
+    want, _, _ = OracleTokenizer(sd, **cfg).forward_discr_loss(v, dsd, dim=64, max_dim=512)
+    assert abs(float(total) - float(want)) <= 5e-4 * max(1., abs(float(want))), (float(total), float(want))
+    assert float(br.gradient_penalty) == 0. and abs(float(br.discr_loss) - float(total)) == 0.
+    with pytest.raises(NotImplementedError):
+        tok(v.cuda(), return_discr_loss=True)
+
+
+def test_hinge_kernel():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    fake, real = torch.randn(37, generator=g) * 2, torch.randn(37, generator=g) * 2
+    out = torch.empty(1, device=ops.device)
+    ops.hinge_discr_loss(fake.to(ops.device), real.to(ops.device), 37, out)(ops.current_stream())
+    ops.synchronize()
+    want = (torch.relu(1 + fake) + torch.relu(1 - real)).mean().item()
+    assert abs(out.item() - want) <= 1e-6 * max(1., want)

@@ -159,3 +159,38 @@ def test_separate_first_frame_encoding_matches_reference():
     assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
     with pytest.raises(RuntimeError):                                # the reference cannot take a single frame in this mode
         ref(torch.randn(1, 3, 1, 16, 16), return_codes=True)
+
+
+# ------------------------------------------------------------------------------- discriminator
+def test_discriminator_restatement_matches_reference():
+    from oracle.ref_loader import load_reference
+    from oracle.restate import discriminator_forward
+    M = load_reference()
+    torch.manual_seed(0)
+    kw = dict(dim=8, image_size=16, channels=3, max_dim=64)
+    ref = M.Discriminator(**kw)
+    x = torch.randn(3, 3, 16, 16)
+    with torch.no_grad():
+        r = ref(x)
+    o = discriminator_forward(x, {'discr.' + k: v for k, v in ref.state_dict().items()}, 'discr.', **kw)
+    assert r.shape == (3,) and torch.allclose(o, r, atol=1e-6, rtol=0)
+
+
+def test_discr_loss_matches_reference():
+    """forward(return_discr_loss=True, apply_gradient_penalty=False) of the reference (M:1730-1782) vs the restated path; the random
+    frame pick uses the CPU default generator in both, so it is seeded identically before each call."""
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    ref = make_reference_tokenizer(**kw, use_gan=True)
+    ref.load_state_dict(sd, strict=False)
+    dsd = {k: v.clone() for k, v in ref.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(77)
+    with torch.no_grad():
+        total, br = ref(v, return_discr_loss=True, apply_gradient_penalty=False)
+    orc = OracleTokenizer(sd, **cfg)
+    torch.manual_seed(77)
+    loss, _, _ = orc.forward_discr_loss(v, dsd, dim=16, max_dim=512)
+    assert torch.allclose(loss, total, atol=2e-6) and torch.allclose(loss, br.discr_loss, atol=2e-6)
+    assert float(br.gradient_penalty) == 0.

@@ -11,7 +11,15 @@ from oracle import thirdparty as TP
 
 
 def _real(name):
-    if importlib.util.find_spec(name) is None:
+    import sys
+    mod = sys.modules.get(name)
+    if mod is not None and getattr(mod, '__file__', None) is None:       # oracle/ref_loader.py's sys.modules shim, not the package
+        pytest.skip(f'{name} is shimmed in this process and not installed: third-party parity stays unpinned')
+    try:
+        spec = importlib.util.find_spec(name)
+    except (ValueError, ImportError):
+        spec = None
+    if spec is None:
         pytest.skip(f'{name} is not installed (expected in this image): third-party parity stays unpinned')
     return importlib.import_module(name)
 
