@@ -99,7 +99,7 @@ extern "C" int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64
 template <typename E, int NV>
 __device__ __forceinline__ void se_pool_rows(const char* __restrict__ base, int C, int G, int l, int p_begin, int p_end, int R,
                                              const float (&wreg)[NV][E::kVec], float bk, float& m_run, float& s_run,
-                                             float (&acc)[NV][E::kVec]) {
+                                             float (&acc)[NV][E::kVec], int nch = 1 << 30) {
     constexpr int KV = E::kVec;
     constexpr int U = 4;
     for (int p0 = p_begin; p0 < p_end; p0 += U * R) {
@@ -108,8 +108,10 @@ __device__ __forceinline__ void se_pool_rows(const char* __restrict__ base, int 
         for (int u = 0; u < U; ++u) {
             const int p = min(p0 + u * R, p_end - 1);       // clamped duplicate rows are masked below
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-                q[u][v] = *(const i32x4*)(base + ((int64_t)p * C + (int64_t)(l + v * G) * KV) * E::kBytes);
+            for (int v = 0; v < NV; ++v) {       // lanes past the row's last chunk (G is the next power of two) read chunk 0 with zero weights
+                const int ch = (l + v * G) < nch ? (l + v * G) : 0;
+                q[u][v] = *(const i32x4*)(base + ((int64_t)p * C + (int64_t)ch * KV) * E::kBytes);
+            }
         }
         float dot[U];
 #pragma unroll
@@ -168,11 +170,12 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const void* __restrict__ y
     const int rows_per_chunk = (P + nchunk - 1) / nchunk;
     const int p_begin = j * rows_per_chunk, p_end = min(P, p_begin + rows_per_chunk);
 
+    const int nch = C / KV;                    // chunks of a row; G >= nch is a power of two when nch < 64 (masked lanes)
     float wreg[NV][KV];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int k = 0; k < KV; ++k) wreg[v][k] = wk[(l + v * G) * KV + k];
+        for (int k = 0; k < KV; ++k) wreg[v][k] = (l + v * G) < nch ? wk[(l + v * G) * KV + k] : 0.f;
 
     float m_run = -INFINITY, s_run = 0.f;
     float acc[NV][KV];
@@ -182,14 +185,14 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const void* __restrict__ y
         for (int k = 0; k < KV; ++k) acc[v][k] = 0.f;
 
     const char* base = (const char*)y + ((int64_t)f * P) * C * E::kBytes;
-    se_pool_rows<E, NV>(base, C, G, l, p_begin + slot, p_end, R, wreg, bk, m_run, s_run, acc);
+    se_pool_rows<E, NV>(base, C, G, l, p_begin + slot, p_end, R, wreg, bk, m_run, s_run, acc, nch);
     // merge the R slots: sm[slot*(C+2)] = {m, s, acc[C]}
     float* mine = sm + slot * (C + 2);
     if (l == 0) { mine[0] = m_run; mine[1] = s_run; }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int k = 0; k < KV; ++k) mine[2 + (l + v * G) * KV + k] = acc[v][k];
+        for (int k = 0; k < KV; ++k) if ((l + v * G) < nch) mine[2 + (l + v * G) * KV + k] = acc[v][k];
     __syncthreads();
     float M = -INFINITY;
     for (int r = 0; r < R; ++r) M = fmaxf(M, sm[r * (C + 2)]);
@@ -216,9 +219,9 @@ extern "C" int mv2_se_pool(int dtype, const void* y, const float* wk, float bk, 
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
     if (C % kvec != 0) return MV2_EINVAL;
     const int nch = C / kvec;
-    int G = nch >= 64 ? 64 : nch;
-    if (!is_pow2(G) || (nch > 64 && nch % 64 != 0)) return MV2_EINVAL;
-    const int NV = nch / G;
+    int G = 64;
+    if (nch < 64) { G = 1; while (G < nch) G <<= 1; }                 // next power of two; lanes >= nch are masked
+    const int NV = (nch + G - 1) / G;                                    // row chunks per lane (the last group may be partly masked)
     if (NV != 1 && NV != 2 && NV != 4) return MV2_EINVAL;
     const size_t lds = (size_t)(256 / G) * (C + 2) * sizeof(float);
     if (lds > 64 * 1024) return MV2_EINVAL;

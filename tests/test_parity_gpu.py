@@ -413,3 +413,30 @@ def test_separate_first_frame_encoding(dtype):
             if torch.equal(codes.cpu(), ocodes):
                 assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
         assert (tok.decode_from_code_indices(ocodes.cuda()).cpu() - orecon).abs().max().item() <= 5e-4
+
+
+# ------------------------------------------------------------------------------- odd shapes: every eligibility rule has a fallback
+ODD_CASES = [
+    # image 48 -> 24 -> 12 -> 6: frames of 36 rows at C = 256 (not a multiple of 32: mv2_pw_se ineligible, generic tail), B = 3
+    dict(kw=dict(image_size=48, init_dim=64, max_dim=256, codebook_size=512, layers=('residual', 'compress_space', ('consecutive_residual', 2),
+                                                                                      'compress_space', 'residual', 'compress_space', 'residual', 'attend_space')), B=3, T=1),
+    # T = 1 video (image path) with time layers present, 2 codebooks, C = 128 / 256 with 64- and 16-row frames
+    dict(kw=dict(image_size=32, init_dim=128, max_dim=256, codebook_size=64, num_codebooks=2,
+                 layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_space', 'residual', 'attend_time')), B=2, T=1),
+    # long clip, small frames: T = 17 at 16 x 16 (frames of 64 / 16 rows), FSQ
+    dict(kw=dict(image_size=16, init_dim=64, max_dim=512, use_fsq=True, fsq_levels=[8, 5, 5, 5],
+                 layers=('residual', 'compress_time', 'residual', 'compress_space', 'compress_time', 'residual', 'linear_attend_space')), B=1, T=17),
+    # width that is not a power of two in the residual stack (no attention layers: C = 96 / 192)
+    dict(kw=dict(image_size=32, init_dim=96, max_dim=192, codebook_size=256, layers=('residual', 'compress_space', 'residual', 'compress_time', 'residual')), B=2, T=5),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', range(len(ODD_CASES)))
+def test_lockstep_odd_shapes(case, dtype):
+    c = ODD_CASES[case]
+    cfg = make_cfg(**c['kw'])
+    sd = init_state_dict(cfg, seed=50 + case, randomize_se=True)
+    s = c['kw']['image_size']
+    v = torch.randn(c['B'], 3, c['T'], s, s, generator=torch.Generator().manual_seed(60 + case))
+    run_lockstep(cfg, sd, v, dtype)
