@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             sg = nxt;
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the step (the scheduler would sink it)
             const char* base = smem + PAR * STAGE;
-            // fragment reads software-pipelined over two register sets (see conv_halo.hip)
+            // fragment reads software-pipelined over two register sets
             i32x4 fw[2][WCO], fp[2][WPOS];
             auto read_frags = [&](int ks, auto set_c) {
                 constexpr int SET = decltype(set_c)::value;
@@ -337,26 +337,10 @@ struct Launch {
     int n_co_tiles, n_pos_tiles, splitk, steps_per_split;
     int64_t M, ws_rows;
     int ws_cols;
-    // halo-tiled variant (conv_halo.hip)
+    // unused by the generic kernel (conv3.hip plans its own tiles); kept zero
     bool halo;
     int th, tw, tiles_h, tiles_w, nchunk, chunks_per_split;
 };
-
-// stride-1 kt x 3 x 3 "same"/causal convolution over whole 128-byte channel chunks -> halo kernel
-inline bool halo_eligible(const mv2_conv_desc& d) {
-#ifndef MV2_EXPERIMENTS
-    (void)d;
-    return false;      // product build: these convolutions are mv2_conv3's (conv3.hip); mv2_conv keeps the generic kernel
-#else
-    static const bool off = getenv("MV2_NO_HALO") != nullptr;
-    if (off) return false;
-    const int es = d.dtype == MV2_BF16 ? 2 : 4;
-    return d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 &&
-           d.pt == d.kt - 1 && d.kt <= 3 && d.check_bounds && d.seg_bytes == 128 && (d.Ci * es) % 128 == 0 &&
-           d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi && d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) &&
-           d.act != MV2_ACT_GEGLU && d.co >= 64;
-#endif
-}
 
 inline int device_cus() {      // of the CURRENT device; not cached: a process may drive several devices
     int dev = 0, n = 0;
@@ -382,64 +366,6 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     Launch L;
     L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
-#ifdef MV2_EXPERIMENTS
-    if (halo_eligible(d)) {
-        L.halo = true;
-        const int es = d.dtype == MV2_BF16 ? 2 : 4;
-        // tile menu of conv_halo.hip.  MV2_HALO_TILE=1 forces 64co x 128pos tiles above 64 channels (twice the
-        // blocks: less tail on the 512 block slots at batch 1, at 1.5 LDS fragment reads per MFMA instead of 1)
-        static const int tile_policy = getenv("MV2_HALO_TILE") ? atoi(getenv("MV2_HALO_TILE")) : 0;
-        if (d.co <= 64) { L.t = {64, 256}; L.th = 16; L.tw = 16; }
-        else if (tile_policy == 1) { L.t = {64, 128}; L.th = 8; L.tw = 16; }
-        else if (tile_policy == 2 && d.Ho >= 16 && d.Wo >= 16) { L.t = {128, 256}; L.th = 16; L.tw = 16; }   // 8 waves, 1 block / CU
-        else { L.t = {128, 128}; L.th = 8; L.tw = 16; }
-        const int slots_per_cu = (L.t.bco == 128 && L.t.bpos == 256) ? 1 : 2;
-        L.tiles_h = (d.Ho + L.th - 1) / L.th;
-        L.tiles_w = (d.Wo + L.tw - 1) / L.tw;
-        L.nchunk = (d.Ci * es) / 128;
-        L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
-        L.n_pos_tiles = d.B * d.To * L.tiles_h * L.tiles_w;
-        int sk = d.splitk;
-        // MV2_HALO_RS=1 (conv_halo_rs.hip, one 8-wave block per CU): pick the split that fills whole rounds of CUs,
-        // charging ~7 % of a launch per extra fp32 slab (write + re-read in conv_finish)
-        const bool rs = getenv("MV2_HALO_RS") != nullptr && d.dtype == MV2_BF16 && L.t.bco == 128 && L.t.bpos == 128;
-        if (sk <= 0 && rs) {
-            const int64_t tiles = (int64_t)L.n_co_tiles * L.n_pos_tiles;
-            const int cus = device_cus();
-            double best = -1.0;
-            sk = 1;
-            for (int cand = 1; cand <= L.nchunk && cand <= 8; ++cand) {
-                const int cps = (L.nchunk + cand - 1) / cand;
-                const int eff_sk = (L.nchunk + cps - 1) / cps;
-                if (eff_sk != cand) continue;
-                const int64_t blocks = tiles * eff_sk;
-                const int64_t rounds = (blocks + cus - 1) / cus;
-                const double score = (double)blocks / (double)(rounds * cus) - 0.07 * (eff_sk - 1);
-                if (score > best + 1e-9) { best = score; sk = eff_sk; }
-            }
-        }
-        if (sk <= 0) {
-            sk = 1;
-            const int64_t blocks = (int64_t)L.n_co_tiles * L.n_pos_tiles;
-            const int cus = device_cus();
-            const int64_t slots = (int64_t)cus * slots_per_cu;
-            if (blocks * 4 < slots * 3) sk = (int)((slots + blocks - 1) / blocks);
-            // ... but when two or more splits FIT one wave of block slots, take the largest that fits instead of
-            // spilling a 25 %-full second wave (C = 512, T = 20: 3 x 160 = 480 blocks, measured 102 -> 97 us;
-            // C = 256 stays at 2 x 320: one split per tile was slower, 105 -> 111 us).  MV2_HALO_SK=0: old rule.
-            static const int sk_policy = getenv("MV2_HALO_SK") ? atoi(getenv("MV2_HALO_SK")) : 1;
-            if (sk_policy == 1 && slots / blocks >= 2) sk = (int)(slots / blocks);
-        }
-        if (sk > L.nchunk) sk = L.nchunk;
-        if (sk < 1) sk = 1;
-        L.chunks_per_split = (L.nchunk + sk - 1) / sk;
-        L.splitk = (L.nchunk + L.chunks_per_split - 1) / L.chunks_per_split;
-        L.steps_per_split = 0;
-        L.ws_rows = L.M;
-        L.ws_cols = L.n_co_tiles * L.t.bco;
-        return L;
-    }
-#endif
     L.t = pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
@@ -482,10 +408,6 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
-#ifdef MV2_EXPERIMENTS
-    if (L.halo) rc = mv2_launch_halo(p, L.t.bco, L.th, L.tw, st);
-    else
-#endif
     if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1>(p, L, st);
     else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1>(p, L, st);
     else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
@@ -538,12 +460,6 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
     p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
     p.ablate = 0;
-#ifdef MV2_EXPERIMENTS
-    {
-        static const int ab = getenv("MV2_ABLATE") ? atoi(getenv("MV2_ABLATE")) : 0;   // timing experiments only: results are wrong
-        p.ablate = ab;
-    }
-#endif
     if (L.splitk > 1) {
         const size_t need = (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
         if (!workspace || workspace_bytes < need) return MV2_EWORKSPACE;
@@ -551,58 +467,6 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == MV2_BF16 ? launch_dtype<BF16>(p, L, st) : launch_dtype<F32>(p, L, st);
 }
-
-#ifdef MV2_EXPERIMENTS
-// round-1 fused kernel, kept in the experiments build as the A/B baseline of mv2_conv3 (tools/k3_bench.cpp)
-// fused 3x3 causal conv + activation + 1x1x1 conv + activation (ResidualUnit front half), bf16, C <= 128
-extern "C" int mv2_conv_pw_eligible(const mv2_conv_desc* d) {
-    if (!d || validate(*d) != MV2_OK) return 0;
-    if (d->dtype != MV2_BF16 || !halo_eligible(*d)) return 0;
-    if (d->co > 128 || (d->co != 64 && d->co != 128) || d->store != MV2_STORE_ROWS || d->out_c != d->co) return 0;
-    if (d->act == MV2_ACT_GEGLU) return 0;
-    return getenv("MV2_NO_FUSE_PW") != nullptr ? 0 : 1;      // read per call (plan-build time only): tests toggle it in-process
-}
-
-extern "C" int mv2_conv_pw_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w) {
-    if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
-    mv2_conv_desc dd = *d;
-    dd.splitk = 1;
-    const Launch L = plan_launch(dd);
-    if (!L.halo) return MV2_EINVAL;
-    if (tile_h) *tile_h = L.th;
-    if (tile_w) *tile_w = L.tw;
-    return L.tiles_h * L.tiles_w;
-}
-
-extern "C" int mv2_conv_pw(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
-                           const float* bias, const void* wp2, const float* bias2, int act2, const float* se_wk, float se_bk,
-                           float* se_part, void* out, void* stream) {
-    if (!d || !in || !wp || !segs || !wp2 || !out) return MV2_EINVAL;
-    if (se_part && !se_wk) return MV2_EINVAL;
-    if (!mv2_conv_pw_eligible(d)) return MV2_EINVAL;
-    if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU && act2 != MV2_ACT_SILU) return MV2_EINVAL;
-    if (in_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
-    if ((int64_t)d->B * d->To * d->Ho * d->Wo >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
-    mv2_conv_desc dd = *d;
-    dd.splitk = 1;                               // the fused stage needs the whole reduction in one block
-    const Launch L = plan_launch(dd);
-    if (!L.halo || L.n_co_tiles != 1 || L.splitk != 1) return MV2_EINVAL;
-    ConvParams p;
-    p.d = dd; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = nullptr; p.residual = nullptr;
-    p.out = out; p.ws = nullptr;
-    p.wp2 = wp2; p.bias2 = bias2; p.act2 = act2;
-    p.se_wk = se_wk; p.se_bk = se_bk; p.se_part = se_part;
-    p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)((size_t)dd.nsteps * dd.co_pad * 128);
-    p.M = L.M; p.lg_seg_chunks = ilog2(dd.seg_bytes / 16);
-    p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;
-    p.steps_per_split = L.steps_per_split; p.splitk = 1;
-    p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
-    p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
-    p.ablate = 0;
-    return mv2_launch_halo(p, L.t.bco, L.th, L.tw, (hipStream_t)stream);
-}
-
-#endif
 
 extern "C" int mv2_abi_version(void) { return MV2_ABI_VERSION; }
 extern "C" int mv2_device_cus(void) {

@@ -25,14 +25,14 @@ struct ConvParams {
     int32_t steps_per_split, splitk;
     int32_t ws_cols;
     int64_t ws_rows;
-    // halo-tiled 3x3 variant (conv_halo.hip)
+    // tile grid of the 3x3 kernel (conv3.hip)
     int32_t tiles_h, tiles_w, nchunk, chunks_per_split;
-    int32_t ablate;   // runtime A/B switches for experiments (env MV2_ABLATE), see conv_halo.hip
-    // fused second stage (mv2_conv_pw): 1x1x1 conv over the block's own output channels
+    int32_t ablate;   // unused (kept zero)
+    // fused second stage (mv2_conv3 with wp2): 1x1x1 conv over the block's own output channels
     const void* wp2;
     const float* bias2;
     int32_t act2;
-    // ... and, optionally, the SqueezeExcite pooling partials of the finished tile (mv2_conv_pw se_part)
+    // ... and, optionally, the SqueezeExcite pooling partials of the finished tile (mv2_conv3 se_part)
     const float* se_wk;
     float se_bk;
     float* se_part;
@@ -43,15 +43,6 @@ struct ConvParams {
     uint32_t ws_bytes;
 };
 
-#ifdef MV2_EXPERIMENTS
-// Round-1 kernels, compiled only into libmv2_hip_exp.so (A/B baselines for tools/; the product library has neither
-// these kernels nor any environment switch):
-// conv_halo.hip: launches the halo-tiled kernel for a (bco, th x tw) tile choice
-int mv2_launch_halo(const ConvParams& p, int bco, int th, int tw, hipStream_t st);
-// conv_halo_rs.hip: role-specialised 8-wave variant (MV2_HALO_RS=1 only)
-bool mv2_halo_rs_eligible(const ConvParams& p, int bco, int th, int tw);
-int mv2_launch_halo_rs(const ConvParams& p, hipStream_t st);
-#endif
 
 // ------------------------------------------------------------------------------- epilogue
 template <typename E>
@@ -164,7 +155,7 @@ __device__ __forceinline__ bool stage_ok(const ConvParams& p) {
     return p.d.store != MV2_STORE_NCTHW_F32 && ((p.d.out_c * es) % 16) == 0 && (p.d.co % (16 / es)) == 0;
 }
 
-// owner: false for waves that hold no accumulators (the load waves of conv_halo_rs.hip); they skip phase 1 and
+// owner: false for waves that hold no accumulators; they skip phase 1 and
 // only help with the row stores of phase 2
 template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typename RowFn>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,

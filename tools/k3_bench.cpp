@@ -1,6 +1,6 @@
 // tools/k3_bench.cpp — standalone A/B + correctness harness for mv2_conv3 (conv3.hip) against
 //   (1) a plain CPU reference (small shapes, fp64 accumulate) and
-//   (2) the round-1 halo kernel (mv2_conv / mv2_conv_pw of libmv2_hip_exp.so) on the real level shapes,
+//   (2) the generic kernel (mv2_conv; and mv2_conv_pw when the library still exports the round-1 fused kernel) on the real level shapes,
 // plus run-to-run determinism, ticket-word hygiene and per-launch timing (HIP events, back-to-back launches).
 // Build (no GPU needed):  hipcc -O2 -std=c++17 tools/k3_bench.cpp -o tools/k3_bench -ldl
 // Run on the GPU box:     tools/k3_bench [path to libmv2_hip_exp.so]
