@@ -11,6 +11,7 @@
 // Activation gathers go through a raw buffer descriptor: a tap that falls into the causal /
 // "same" zero padding is redirected to offset = num_records, for which the hardware returns 0,
 // so the halo costs no VALU selects and no branches.
+#include <cstdio>
 #include <cstdlib>
 #include "conv_common.h"
 
@@ -316,6 +317,12 @@ inline TileCfg pick_tile(const mv2_conv_desc& d) {
     static const int small_policy = getenv("MV2_SMALL_TILE") ? atoi(getenv("MV2_SMALL_TILE")) : 2;
 #else
     constexpr int small_policy = 2;
+#endif
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_TILE")) {        // tools/k3_bench tile sweep: "bco,bpos" (read per call)
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && !(d.act == MV2_ACT_GEGLU && a == 32)) return {a, b};
+    }
 #endif
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     const int64_t blocks128 = ((d.co + 127) / 128) * ((M + 127) / 128);

@@ -350,16 +350,22 @@ int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[2], "generic")) {
         hipStream_t st2; CK(hipStreamCreate(&st2));
         p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
-        time_pointwise("k1 C=512 T=20", 20, 16, 512, 512, MV2_ACT_ELU, false, st2);
-        time_pointwise("k1 C=512 T=5", 5, 16, 512, 512, MV2_ACT_ELU, false, st2);
-        time_pointwise("k1 C=256 T=20", 20, 32, 256, 256, MV2_ACT_ELU, false, st2);
-        time_pointwise("k1 C=128 T=20", 20, 64, 128, 128, MV2_ACT_ELU, false, st2);
-        time_pointwise("ff1 C=512 T=20 (geglu)", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
-        time_pointwise("ff2 C=512 T=20", 20, 16, 1408, 512, MV2_ACT_NONE, true, st2);
-        time_pointwise("ff1 C=256 T=20 (geglu)", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2);
-        time_pointwise("ff2 C=256 T=20", 20, 32, 704, 256, MV2_ACT_NONE, true, st2);
-        time_pointwise("qkv C=512 T=20", 20, 16, 512, 768, MV2_ACT_NONE, false, st2);
-        time_pointwise("out C=512 T=20", 20, 16, 256, 512, MV2_ACT_NONE, true, st2);
+        const char* tiles[] = {"", "64,64", "64,128", "128,128", "64,256", "32,256"};
+        for (const char* tl : tiles) {
+            if (*tl) setenv("MV2_TILE", tl, 1); else unsetenv("MV2_TILE");
+            printf("---- tile %s\n", *tl ? tl : "(default rule)");
+            time_pointwise("ff1 C=512 T=20 (geglu)", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
+            time_pointwise("ff2 C=512 T=20", 20, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+            time_pointwise("ff1 C=256 T=20 (geglu)", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2);
+            time_pointwise("ff2 C=256 T=20", 20, 32, 704, 256, MV2_ACT_NONE, true, st2);
+            time_pointwise("ff1 C=512 T=5 (geglu)", 5, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
+            time_pointwise("ff2 C=512 T=5", 5, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+            time_pointwise("qkv C=512 T=20", 20, 16, 512, 768, MV2_ACT_NONE, false, st2);
+            time_pointwise("out C=512 T=20", 20, 16, 256, 512, MV2_ACT_NONE, true, st2);
+            time_pointwise("kv C=256 T=20", 20, 32, 256, 256, MV2_ACT_NONE, false, st2);
+            time_pointwise("ff1 B=4 C=512 T=20 (geglu)", 80, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
+            time_pointwise("ff2 B=4 C=512 T=20", 80, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        }
         return 0;
     }
     const bool quick = argc > 2 && (!strcmp(argv[2], "quick") || !strcmp(argv[2], "levels"));
