@@ -444,3 +444,25 @@ def test_forward_return_discr_loss_matches_oracle():
     assert abs(float(total) - float(want)) <= 2e-6 and float(br.gradient_penalty) == 0.
     with pytest.raises(NotImplementedError):
         tok(v, return_discr_loss=True)                               # gradient penalty (the reference's default) needs autograd
+
+
+def test_c_consumer_builds_and_runs(tmp_path):
+    """include/mv2.h is a plain C99 header and the library is usable from C without Python (the drop-in boundary of the brief):
+    tests/abi/abi_smoke.c is compiled with gcc against the header, linked with libmv2_hip.so and run (no kernel launch)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    lib_dir = os.path.join(ROOT, 'magvit2_pytorch_amd')
+    assert os.path.exists(os.path.join(lib_dir, 'libmv2_hip.so')), 'build the library first (python -m magvit2_pytorch_amd.build)'
+    exe = str(tmp_path / 'abi_smoke')
+    hdr = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-x', 'c',
+                          os.path.join(ROOT, 'include', 'mv2.h')], capture_output=True, text=True)
+    assert hdr.returncode == 0, hdr.stderr
+    cc = subprocess.run([gcc, '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'abi', 'abi_smoke.c'),
+                         '-L', lib_dir, '-l:libmv2_hip.so', '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and 'abi smoke ok' in run.stdout, (run.returncode, run.stdout, run.stderr)
