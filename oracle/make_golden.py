@@ -111,6 +111,81 @@ def generate(name):
           f'({os.path.getsize(path) / 1024:.0f} KiB)')
 
 
+
+
+# ----------------------------------------------------------------------------- feature fixtures
+# Small cases of the paths beyond eval encode / decode, again produced by the REFERENCE ITSELF.  Weights come from
+# init_state_dict / the discriminator param specs (seeded), inputs from seeds; the fixture stores the reference's outputs.
+FEATURES = {
+    'feat_loss': dict(kw=dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS), shape=(2, 3, 5, 32, 32), wseed=13, dseed=14),
+    'feat_loss_2cb': dict(kw=dict(image_size=32, init_dim=8, max_dim=32, codebook_size=64, num_codebooks=2,
+                                  layers=('residual', 'compress_space', ('consecutive_residual', 2), 'attend_space', 'compress_time', 'attend_time')),
+                          shape=(2, 3, 5, 32, 32), wseed=13, dseed=14),
+    'feat_cond_residual': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, dim_cond=8,
+                                       layers=('residual', 'compress_space', 'cond_residual', 'cond_residual')), shape=(2, 3, 5, 16, 16), wseed=3, dseed=1, cseed=2),
+    'feat_sep_first_frame': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+                                         layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
+                                 shape=(2, 3, 9, 16, 16), wseed=4, dseed=1),
+    'feat_discr': dict(kw=dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual')),
+                       shape=(3, 3, 5, 16, 16), wseed=5, dseed=6, discr_seed=9, pick_seed=77),
+}
+
+
+def discr_state_dict(dim, image_size, seed):
+    """seeded discriminator weights under the reference's `discr.*` names (init families of the reference's modules)."""
+    from magvit2_pytorch_amd.discriminator import discriminator_param_specs
+    from magvit2_pytorch_amd.spec import init_tensor
+    gen = torch.Generator().manual_seed(seed)
+    return {'discr.' + ps.name: init_tensor(ps, gen) for ps in discriminator_param_specs(dim=dim, image_size=image_size, channels=3, max_dim=512)}
+
+
+def generate_feature(name):
+    f = FEATURES[name]
+    kw, shape = f['kw'], f['shape']
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=f['wseed'], randomize_se=True)
+    video = make_input(shape, f['dseed'])
+    out = dict(cfg=json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}), shape=np.array(shape),
+               weights_sha256=weights_sha(sd), input_sha256=sha_tensors([video]), torch_version=torch.__version__)
+    f32 = lambda t: np.float64(float(t))
+    if name.startswith('feat_loss'):
+        ref = make_reference_tokenizer(**kw)
+        ref.load_state_dict(sd, strict=False)
+        for mode in ('train', 'eval'):
+            ref.train(mode == 'train')
+            with torch.no_grad():
+                total, br = ref(video, return_loss=True)
+            qb = br.quantizer_loss_breakdown
+            out.update({f'{mode}_total': f32(total), f'{mode}_recon': f32(br.recon_loss), f'{mode}_aux': f32(torch.as_tensor(br.lfq_aux_loss)),
+                        f'{mode}_per_sample_entropy': f32(torch.as_tensor(qb.per_sample_entropy)),
+                        f'{mode}_batch_entropy': f32(torch.as_tensor(qb.batch_entropy)), f'{mode}_commitment': f32(torch.as_tensor(qb.commitment))})
+    elif name == 'feat_discr':
+        ref = make_reference_tokenizer(**kw, use_gan=True)
+        dsd = discr_state_dict(16, kw['image_size'], f['discr_seed'])
+        missing, unexpected = ref.load_state_dict({**sd, **dsd}, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        images = make_input((3, 3, 16, 16), f['dseed'] + 1)
+        with torch.no_grad():
+            logits = ref.discr(images)
+            torch.manual_seed(f['pick_seed'])
+            total, br = ref(video, return_discr_loss=True, apply_gradient_penalty=False)
+        out.update(discr_sha256=weights_sha(dsd), logits=logits.numpy().astype(np.float32), discr_loss=f32(total))
+    else:
+        ref = make_reference_tokenizer(**kw)
+        missing, unexpected = ref.load_state_dict(sd, strict=False)
+        assert not unexpected and all(m.startswith('discr.') for m in missing), (missing, unexpected)
+        cond = make_input((shape[0], kw['dim_cond']), f['cseed']) if 'cseed' in f else None
+        ckw = dict(cond=cond) if cond is not None else {}
+        with torch.no_grad():
+            codes, recon = ref(video, return_codes=True, return_recon=True, **ckw)
+            dec = ref.decode_from_code_indices(codes, **ckw)
+        assert torch.equal(dec, recon)
+        out.update(codes=codes.numpy(), recon=recon.numpy().astype(np.float32))
+    path = os.path.join(GOLDEN_DIR, f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
 if __name__ == '__main__':
-    for n in (sys.argv[1:] or CASES):
-        generate(n)
+    for n in (sys.argv[1:] or list(CASES) + list(FEATURES)):
+        (generate_feature if n in FEATURES else generate)(n)

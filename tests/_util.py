@@ -44,3 +44,38 @@ class Golden:
 
 def live_cfg(**kw):
     return make_cfg(**kw)
+
+
+class Feature:
+    """tests/golden/feat_*.npz (oracle/make_golden.py FEATURES): outputs of the reference itself on the paths beyond eval
+    encode / decode; weights and inputs are regenerated from the seeds recorded in oracle.make_golden.FEATURES."""
+
+    def __init__(self, name):
+        from oracle.make_golden import FEATURES
+        self.name, self.f = name, FEATURES[name]
+        self.z = np.load(os.path.join(GOLDEN_DIR, f'{name}.npz'), allow_pickle=False)
+        self.kw = dict(self.f['kw'])
+        self.cfg = make_cfg(**self.kw)
+        self.shape = tuple(self.f['shape'])
+
+    def weights(self):
+        sd = init_state_dict(self.cfg, seed=self.f['wseed'], randomize_se=True)
+        assert weights_sha(sd) == str(self.z['weights_sha256']), 'seeded weights are not reproducible on this box'
+        return sd
+
+    def video(self):
+        v = make_input(self.shape, self.f['dseed'])
+        assert sha_tensors([v]) == str(self.z['input_sha256'])
+        return v
+
+    def cond(self):
+        return make_input((self.shape[0], self.kw['dim_cond']), self.f['cseed']) if 'cseed' in self.f else None
+
+    def discr_weights(self):
+        from oracle.make_golden import discr_state_dict
+        dsd = discr_state_dict(16, self.kw['image_size'], self.f['discr_seed'])
+        assert weights_sha(dsd) == str(self.z['discr_sha256'])
+        return dsd
+
+    def scalar(self, key):
+        return float(self.z[key])

@@ -466,3 +466,45 @@ def test_c_consumer_builds_and_runs(tmp_path):
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and 'abi smoke ok' in run.stdout, (run.returncode, run.stdout, run.stderr)
+
+
+# ------------------------------------------------------------------------------- facade (CPU emulation of the kernels) vs the reference's own outputs
+def test_facade_vs_reference_feature_fixtures():
+    """tests/golden/feat_*.npz hold outputs of the reference itself for the paths beyond eval encode / decode (oracle/make_golden.py
+    FEATURES); the facade's lowering, run on the kernel emulation in fp32, must reproduce them.  The GPU twin of this test is
+    tests/test_losses_gpu.py::test_product_vs_reference_feature_fixtures."""
+    from magvit2_pytorch_amd.discriminator import Discriminator
+    from oracle.make_golden import make_input
+    from tests._util import Feature
+    for name in ('feat_loss', 'feat_loss_2cb'):
+        f = Feature(name)
+        tok = VideoTokenizer(**f.kw, use_gan=False, perceptual_loss_weight=0., seed=0)
+        tok.load_state_dict(f.weights())
+        tok._set_backend(CpuOps())
+        tok.compute_dtype = torch.float32
+        for mode in ('train', 'eval'):
+            tok.train(mode == 'train')
+            total, br = tok(f.video(), return_loss=True)
+            assert abs(float(total) - f.scalar(f'{mode}_total')) <= 1e-5 * max(1., abs(f.scalar(f'{mode}_total'))), (name, mode)
+            assert abs(float(br.lfq_aux_loss) - f.scalar(f'{mode}_aux')) <= 1e-5
+    for name in ('feat_cond_residual', 'feat_sep_first_frame'):
+        f = Feature(name)
+        tok = emulated_tokenizer(dict(f.kw, use_gan=False), f.weights(), torch.float32)
+        ckw = dict(cond=f.cond()) if f.cond() is not None else {}
+        codes, recon = tok(f.video(), return_codes=True, return_recon=True, **ckw)
+        assert torch.equal(codes, torch.from_numpy(f.z['codes']))
+        assert (recon - torch.from_numpy(f.z['recon'])).abs().max().item() <= 2e-5
+    f = Feature('feat_discr')
+    d = Discriminator(dim=16, image_size=16, channels=3, max_dim=512, seed=0)
+    d.load_state_dict({k[len('discr.'):]: v for k, v in f.discr_weights().items()})
+    d._set_backend(CpuOps())
+    d.compute_dtype = torch.float32
+    logits = d(make_input((3, 3, 16, 16), f.f['dseed'] + 1))
+    assert (logits - torch.from_numpy(f.z['logits'])).abs().max().item() <= 5e-6
+    tok = VideoTokenizer(**f.kw, seed=0)
+    tok.load_state_dict({**f.weights(), **f.discr_weights()})
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    torch.manual_seed(f.f['pick_seed'])
+    total, _ = tok(f.video(), return_discr_loss=True, apply_gradient_penalty=False)
+    assert abs(float(total) - f.scalar('discr_loss')) <= 1e-5

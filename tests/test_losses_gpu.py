@@ -197,3 +197,50 @@ def test_hinge_kernel():
     ops.synchronize()
     want = (torch.relu(1 + fake) + torch.relu(1 - real)).mean().item()
     assert abs(out.item() - want) <= 1e-6 * max(1., want)
+
+
+# ------------------------------------------------------------------------------- product vs the reference's own outputs (feature fixtures)
+def test_product_vs_reference_feature_fixtures():
+    """fp32 mode on the GPU against tests/golden/feat_*.npz (outputs of the reference itself, oracle/make_golden.py FEATURES):
+    losses in train / eval mode, cond_residual, separate_first_frame_encoding, discriminator logits and hinge loss."""
+    from magvit2_pytorch_amd.discriminator import Discriminator
+    from oracle.make_golden import make_input
+    from tests._util import Feature
+    for name in ('feat_loss', 'feat_loss_2cb'):
+        f = Feature(name)
+        tok = VideoTokenizer(**f.kw, use_gan=False, perceptual_loss_weight=0., seed=0)
+        tok.load_state_dict(f.weights())
+        tok = tok.cuda()
+        tok.compute_dtype = torch.float32
+        for mode in ('train', 'eval'):
+            tok.train(mode == 'train')
+            total, br = tok(f.video().cuda(), return_loss=True)
+            assert abs(float(total) - f.scalar(f'{mode}_total')) <= 3e-4 * max(1., abs(f.scalar(f'{mode}_total'))), (name, mode)
+            assert abs(float(br.recon_loss) - f.scalar(f'{mode}_recon')) <= 1e-4 * f.scalar(f'{mode}_recon')
+            assert abs(float(br.lfq_aux_loss) - f.scalar(f'{mode}_aux')) <= 2e-4
+    for name in ('feat_cond_residual', 'feat_sep_first_frame'):
+        f = Feature(name)
+        tok = VideoTokenizer(**f.kw, use_gan=False, seed=0)
+        tok.load_state_dict(f.weights())
+        tok = tok.cuda()
+        tok.compute_dtype = torch.float32
+        ckw = dict(cond=f.cond().cuda()) if f.cond() is not None else {}
+        codes, recon = tok(f.video().cuda(), return_codes=True, return_recon=True, **ckw)
+        want = torch.from_numpy(f.z['codes'])
+        assert (codes.cpu() != want).float().mean().item() <= 0.005
+        if torch.equal(codes.cpu(), want):
+            assert (recon.cpu() - torch.from_numpy(f.z['recon'])).abs().max().item() <= 5e-4
+    f = Feature('feat_discr')
+    d = Discriminator(dim=16, image_size=16, channels=3, max_dim=512, seed=0)
+    d.load_state_dict({k[len('discr.'):]: v for k, v in f.discr_weights().items()})
+    d = d.cuda()
+    d.compute_dtype = torch.float32
+    logits = d(make_input((3, 3, 16, 16), f.f['dseed'] + 1).cuda()).cpu()
+    assert (logits - torch.from_numpy(f.z['logits'])).abs().max().item() <= 2e-4
+    tok = VideoTokenizer(**f.kw, seed=0)
+    tok.load_state_dict({**f.weights(), **f.discr_weights()})
+    tok = tok.cuda()
+    tok.compute_dtype = torch.float32
+    torch.manual_seed(f.f['pick_seed'])
+    total, _ = tok(f.video().cuda(), return_discr_loss=True, apply_gradient_penalty=False)
+    assert abs(float(total) - f.scalar('discr_loss')) <= 5e-4 * max(1., abs(f.scalar('discr_loss')))
