@@ -497,6 +497,9 @@ class VideoTokenizer(nn.Module):
         if self.separate_first_frame_encoding:
             raise NotImplementedError('forward(return_loss=True) with separate_first_frame_encoding is not built (the loss kernels read one recon buffer)')
         train = self.training and not self.use_fsq
+        if train and self.cfg['codebook_size'] > 4096:
+            raise NotImplementedError('the training-mode entropy loss enumerates the codebook per token; mv2_lfq_stats supports '
+                                      'codebook_size <= 4096 per codebook (use eval mode, or more codebooks of <= 12 bits)')
         plan, key = self._plan(video.shape[0], video.shape[2], train=train)
         self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])

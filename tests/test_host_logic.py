@@ -304,6 +304,19 @@ def test_forward_return_loss_matches_oracle(training):
     assert recon.shape == v.shape and abs(float(loss) - float((recon - v).pow(2).mean())) <= 1e-6
 
 
+def test_forward_return_loss_large_codebook_is_refused_in_train_mode():
+    tok = VideoTokenizer(image_size=16, init_dim=16, max_dim=16, codebook_size=2 ** 13, layers=('residual',), use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    v = torch.zeros(1, 3, 1, 16, 16)
+    tok.train()
+    with pytest.raises(NotImplementedError):
+        tok(v, return_loss=True)
+    tok.eval()
+    total, br = tok(v, return_loss=True)                            # eval mode: no codebook enumeration, aux = 0
+    assert float(br.lfq_aux_loss) == 0.
+
+
 def test_forward_return_loss_refuses_gan_and_perceptual_terms():
     tok = VideoTokenizer(image_size=32, init_dim=16, max_dim=64, codebook_size=256, layers=README_LAYERS, seed=0)   # reference defaults: GAN + VGG
     tok._set_backend(CpuOps())
