@@ -212,13 +212,17 @@ def _se_two_launch(Pn, C, hidden, dtype) -> bool:
 
 
 class Plan:
-    def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False, train: bool = False):
+    def __init__(self, pm: PackedModel, B: int, T: int, H: int, W: int, want_prequant: bool = False, train: bool = False,
+                 headless: bool = False):
+        """headless = the reference's video_contains_first_frame=False (M:1530-1538, 1604, 1646): no time_padding zero frames in
+        front of the clip, nothing cropped after conv_out, the first frame is not encoded separately."""
         self.pm, self.ops, self.cfg = pm, pm.ops, pm.cfg
         self.dtype, self.dt = pm.dtype, pm.dt
         self.B, self.T, self.H, self.W = B, T, H, W
         self.arena = _Arena(self.ops)
         self.tdf = 2 ** sum(s.kind == 'compress_time' for s in pm.stages)
-        self.time_padding = self.tdf - 1
+        self.headless = bool(headless)
+        self.time_padding = 0 if self.headless else self.tdf - 1
         self.train = train and not pm.use_fsq        # training-mode LFQ: straight-through forward value + entropy / commitment aux loss
         want_prequant = want_prequant or self.train
         self.want_prequant = want_prequant
@@ -230,7 +234,7 @@ class Plan:
         # static I/O
         self.video_in = ops.empty((B, ch, T, H, W), torch.float32)
         self.recon = ops.empty((B, ch, T, H, W), torch.float32)
-        self.sep = pm.separate_first_frame
+        self.sep = pm.separate_first_frame and not self.headless
         if self.sep:
             assert T >= 2, 'separate_first_frame_encoding needs at least two frames (the reference fails on a single frame: conv_in gets an empty clip)'
             # edge buffers: the facade splits the clip into its first frame and the rest and joins the two reconstructions
@@ -265,8 +269,17 @@ class Plan:
         self.loss_steps: List = []
         n = self.video_in.numel()
         self.sq_sum = ops.empty((1,), torch.float32)
+        self.sq_sum_rest = None
         sq_ws = ops.empty((max(1, ops.sq_diff_workspace_bytes(n) // 4),), torch.float32)
-        self.loss_steps.append(ops.sq_diff_sum(self.video_in, self.recon, n, self.sq_sum, sq_ws))
+        if self.sep:
+            # the reconstruction lives in two buffers (first frame | rest, M:1633-1639): two sums of squared differences
+            n1 = self.video_first.numel()
+            self.sq_sum_rest = ops.empty((1,), torch.float32)
+            self.loss_steps.append(ops.sq_diff_sum(self.video_first, self.recon_first, n1, self.sq_sum, sq_ws))
+            self.loss_steps.append(ops.sq_diff_sum(self.video_rest, self.recon_rest, n - n1, self.sq_sum_rest, sq_ws))
+        else:
+            self.loss_steps.append(ops.sq_diff_sum(self.video_in, self.recon, n, self.sq_sum, sq_ws))
+        self.n_recon_steps = len(self.loss_steps)
         self.lfq_sums = self.lfq_losses = None
         if self.train:
             K = 1 << pm.cb_dim

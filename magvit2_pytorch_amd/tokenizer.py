@@ -6,9 +6,12 @@ Kept from the reference: the keyword-only constructor and its layer-spec tuple g
 ``state_dict`` key names and shapes (checkpoints load both ways), and the method surface
 ``encode / decode / tokenize / decode_from_code_indices / forward`` with the same tensor conventions
 (NCTHW video or NCHW image in, ids ``(B, T', H', W')`` int64 for LFQ / int32 for FSQ) and the same
-assertions.  ``forward(return_loss=True)`` returns the reconstruction + quantizer auxiliary losses (forward values, computed
-on the device; use_gan=False, perceptual_loss_weight=0).  GAN / VGG losses, backward, conditioning and gateloop layers are out
-of scope here and raise ``NotImplementedError``.
+assertions.  ``forward(return_loss=True)`` returns the reconstruction + quantizer auxiliary losses and, with ``use_gan``, the
+generator's hinge loss through the image discriminator (forward values, computed on the device; adaptive weights are the
+constant 1 the reference uses without a VGG); ``forward(return_discr_loss=True, apply_gradient_penalty=False)`` the
+discriminator's hinge loss incl. caller-supplied multiscale discriminators.  ``video_contains_first_frame=False`` (headless
+clips) is supported on every method.  Backward, the gradient penalty, the gradient-norm adaptive weight (training mode with a
+VGG) and gateloop layers are out of scope here and raise ``NotImplementedError``.
 
 Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode) or
 torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode).  Default: bf16 when called
@@ -145,8 +148,17 @@ class VideoTokenizer(nn.Module):
         self.lfq_diversity_gamma = float(lfq_diversity_gamma)
         self.adversarial_loss_weight = float(adversarial_loss_weight)
         self.has_gan = self.use_gan and self.adversarial_loss_weight > 0.                       # reference :1427
-        if len(multiscale_discrs) > 0:
-            raise NotImplementedError('multiscale discriminators are outside this build')
+        self.grad_penalty_loss_weight = float(grad_penalty_loss_weight)
+        # multiscale discriminators are caller-supplied modules on whole clips (reference :1085, 1431-1441); they run as the
+        # torch modules they are, on the tokenizer's device, and only their logits enter the hinge-loss kernel
+        self.multiscale_adversarial_loss_weight = float(multiscale_adversarial_loss_weight)
+        self.has_multiscale_gan = self.use_gan and self.multiscale_adversarial_loss_weight > 0.
+        self.multiscale_discrs = nn.ModuleList([*multiscale_discrs])
+        self.has_multiscale_discrs = self.has_multiscale_gan and len(self.multiscale_discrs) > 0
+        # perceptual loss (reference :1392-1407): the reference builds torchvision's VGG16 when none is passed; torchvision is
+        # not a dependency here, so the perceptual term needs a caller-supplied `vgg` module
+        self.use_vgg = channels in {1, 3, 4} and self.perceptual_loss_weight > 0.
+        self.vgg = vgg if self.use_vgg else None
         self._validate_widths(channels, stages=S.parse_layers(self.cfg['layers'], init_dim, max_dim))
         self.channels = channels
         self.image_size = image_size
@@ -209,10 +221,14 @@ class VideoTokenizer(nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kw):
         """Accepts a reference state_dict unchanged: discriminator / VGG entries are ignored."""
         has_discr = self.discr is not None and any(k.startswith('discr.') for k in state_dict)
-        sd = {k: v for k, v in state_dict.items()
-              if not ((k.startswith('discr.') and not has_discr) or k.startswith('vgg.') or k.startswith('multiscale_discrs.'))}
+        drop = lambda k: ((k.startswith('discr.') and not has_discr) or (k.startswith('vgg.') and self.vgg is None)
+                          or (k.startswith('multiscale_discrs.') and len(self.multiscale_discrs) == 0))
+        sd = {k: v for k, v in state_dict.items() if not drop(k)}
         if self.discr is not None and not has_discr:          # tokenizer-only checkpoint: the discriminator keeps its weights
             sd.update({'discr.' + k: v for k, v in self.discr.state_dict().items()})
+        for name, mod in (('vgg', self.vgg), ('multiscale_discrs', self.multiscale_discrs)):       # likewise the caller's modules
+            if isinstance(mod, nn.Module) and not any(k.startswith(name + '.') for k in state_dict):
+                sd.update({f'{name}.{k}': v for k, v in mod.state_dict().items()})
         out = super().load_state_dict(sd, strict=strict, **kw)
         self.refresh_weights()
         if self.discr is not None:
@@ -281,7 +297,7 @@ class VideoTokenizer(nn.Module):
             return torch.bfloat16
         return torch.float32
 
-    def _plan(self, B, T, want_prequant=False, train=False) -> Plan:
+    def _plan(self, B, T, want_prequant=False, train=False, headless=False) -> Plan:
         ops = self._backend()
         dt = self._dtype()
         kpm = (dt, self._weights_version)
@@ -289,14 +305,14 @@ class VideoTokenizer(nn.Module):
             sd = {n: self.get_parameter(n) if n != 'quantizers.mask' else self.get_buffer(n) for n in self._param_names}
             self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops)
         train = bool(train) and not self.use_fsq
-        kp = (dt, self._weights_version, B, T, want_prequant or train, train)
+        kp = (dt, self._weights_version, B, T, want_prequant or train, train, bool(headless))
         if kp not in self._plans:
             while len(self._plans) >= self.max_cached_plans:      # LRU: a plan owns an activation arena and up to 4 HIP graphs
                 old = next(iter(self._plans))
                 del self._plans[old]
                 for gk in [gk for gk in self._graphs if gk[0] == old]:
                     del self._graphs[gk]
-            self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant, train)
+            self._plans[kp] = Plan(self._packed[kpm], B, T, self.image_size, self.image_size, want_prequant, train, headless=headless)
         else:
             self._plans[kp] = self._plans.pop(kp)                  # most recently used last
         return self._plans[kp], kp
@@ -332,15 +348,23 @@ class VideoTokenizer(nn.Module):
             g.replay()
 
     # ------------------------------------------------------------------ helpers
-    def _check_video(self, video_or_images):
+    def _check_video(self, video_or_images, video_contains_first_frame=True):
+        """-> (5-D video, video_contains_first_frame); an image is a one-frame clip that contains its first frame (reference :1681-1685)"""
         assert video_or_images.ndim in {4, 5}                                     # reference :1675
         assert video_or_images.shape[-2:] == (self.image_size, self.image_size)   # reference :1677
-        video = video_or_images.unsqueeze(2) if video_or_images.ndim == 4 else video_or_images
-        frames = video.shape[2]
-        assert (frames - 1) % self.time_downsample_factor == 0, \
-            f'number of frames {frames} minus the first frame ({frames - 1}) must be divisible by the total downsample factor across time {self.time_downsample_factor}'
+        if video_or_images.ndim == 4:
+            video, video_contains_first_frame = video_or_images.unsqueeze(2), True
+        else:
+            video = video_or_images
+        frames, first = video.shape[2], int(bool(video_contains_first_frame))
+        assert (frames - first) % self.time_downsample_factor == 0, \
+            f'number of frames {frames} minus the first frame ({frames - first}) must be divisible by the total downsample factor across time {self.time_downsample_factor}'   # reference :1691
         assert video.shape[1] == self.channels
-        return video
+        return video, bool(video_contains_first_frame)
+
+    def _latent_to_frames(self, Tl, video_contains_first_frame):
+        f = self.time_downsample_factor
+        return (Tl - 1) * f + 1 if video_contains_first_frame else Tl * f
 
     def _set_cond(self, plan: Plan, cond, batch):
         # reference :1542-1548 / :1610-1616
@@ -369,12 +393,16 @@ class VideoTokenizer(nn.Module):
         t = act.t[: act.rows * act.C].reshape(act.B, act.T, act.H, act.W, act.C).permute(0, 4, 1, 2, 3)
         return t.contiguous() if dtype is None else t.to(dtype).contiguous()
 
+    def _recon_loss(self, plan: Plan):
+        """F.mse_loss(video, recon) (reference :1722) from the device-side sums of squared differences"""
+        sq = plan.sq_sum[0] if plan.sq_sum_rest is None else plan.sq_sum[0] + plan.sq_sum_rest[0]
+        return sq / plan.video_in.numel()
+
     # ------------------------------------------------------------------ API
     @torch.no_grad()
     def encode(self, video, quantize=False, cond=None, video_contains_first_frame=True):
-        assert video_contains_first_frame, 'headless videos are out of scope'
-        video = self._check_video(video)
-        plan, key = self._plan(video.shape[0], video.shape[2])
+        video, vcff = self._check_video(video, video_contains_first_frame)
+        plan, key = self._plan(video.shape[0], video.shape[2], headless=not vcff)
         self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
         if not quantize:
@@ -388,10 +416,8 @@ class VideoTokenizer(nn.Module):
 
     @torch.no_grad()
     def decode(self, quantized, cond=None, video_contains_first_frame=True):
-        assert video_contains_first_frame
         B, C, Tl, Hl, Wl = quantized.shape
-        T = (Tl - 1) * self.time_downsample_factor + 1
-        plan, key = self._plan(B, T)
+        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame)
         self._set_cond(plan, cond, B)
         q = plan.quantized
         assert (C, Tl, Hl, Wl) == (q.C, q.T, q.H, q.W)
@@ -402,7 +428,6 @@ class VideoTokenizer(nn.Module):
     @torch.no_grad()
     def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):
         assert codes.dtype in (torch.long, torch.int32)                           # reference :1585
-        assert video_contains_first_frame
         ncb = self.cfg['num_codebooks']
         if codes.ndim == 2:
             video_code_len = codes.shape[-1]
@@ -410,8 +435,7 @@ class VideoTokenizer(nn.Module):
                 f'flattened video ids must have a length ({video_code_len}) that is divisible by the fmap size ({self.fmap_size}) squared ({self.fmap_size ** 2})'
             codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
         B, Tl = codes.shape[0], codes.shape[1]
-        T = (Tl - 1) * self.time_downsample_factor + 1
-        plan, key = self._plan(B, T)
+        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame)
         plan.ids_in.copy_(codes.reshape(-1, ncb))
         self._set_cond(plan, cond, B)
         self._run(plan, key, 'codes+dec', [plan.codes_steps, plan.dec_steps])
@@ -426,24 +450,29 @@ class VideoTokenizer(nn.Module):
                 return_discr_loss=False, return_recon_loss_only=False, apply_gradient_penalty=True,
                 video_contains_first_frame=True, adversarial_loss_weight=None, multiscale_adversarial_loss_weight=None,
                 return_prequant=False):
+        adversarial_loss_weight = self.adversarial_loss_weight if adversarial_loss_weight is None else adversarial_loss_weight     # reference :1671-1672
+        multiscale_adversarial_loss_weight = (self.multiscale_adversarial_loss_weight if multiscale_adversarial_loss_weight is None
+                                              else multiscale_adversarial_loss_weight)
         assert (return_loss + return_codes + return_discr_loss) <= 1              # reference :1674
         if return_discr_loss:
             assert self.has_gan and _exists(self.discr)                               # reference :1731-1732
             if apply_gradient_penalty:
                 raise NotImplementedError('the gradient penalty differentiates the discriminator (reference :102-116); this build has '
                                           'forward values only: pass apply_gradient_penalty=False')
-        if return_loss and (self.use_gan or self.perceptual_loss_weight > 0.):
-            raise NotImplementedError('forward(return_loss=True) covers the reconstruction + quantizer auxiliary losses only: '
-                                      'construct with use_gan=False, perceptual_loss_weight=0. (VGG / discriminators are outside '
-                                      'the hot-path scope of this build, SURVEY.md §8f)')
-        assert video_contains_first_frame
-        video = self._check_video(video_or_images)
+        if return_loss:
+            if self.use_vgg and self.vgg is None:
+                raise NotImplementedError('the perceptual term needs a VGG: the reference builds torchvision.models.vgg16 (:1397-1403), which is '
+                                          'not a dependency here; pass `vgg=<module>` or construct with perceptual_loss_weight=0.')
+            if self.training and self.use_vgg and (self.has_gan or self.has_multiscale_discrs):
+                raise NotImplementedError('training mode with a VGG and a GAN weighs the adversarial terms by a ratio of gradient norms '
+                                          '(reference :1819-1842): autograd, outside this forward-only build; call in eval mode')
+        video, vcff = self._check_video(video_or_images, video_contains_first_frame)
         with torch.no_grad():
             if return_loss:
-                return self._forward_loss(video, cond)
+                return self._forward_loss(video, cond, vcff, adversarial_loss_weight, multiscale_adversarial_loss_weight)
             if return_discr_loss:
-                return self._forward_discr_loss(video, cond)
-            plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant)
+                return self._forward_discr_loss(video, cond, vcff)
+            plan, key = self._plan(video.shape[0], video.shape[2], want_prequant=return_prequant, headless=not vcff)
             self._set_video(plan, video)
             self._set_cond(plan, cond, video.shape[0])
             if return_codes and not return_recon:
@@ -451,60 +480,74 @@ class VideoTokenizer(nn.Module):
                 codes = self._ids_out(plan)
                 return (codes, plan.prequant.clone()) if return_prequant else codes
             self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
-            recon = self._recon_out(plan)
-            if video_or_images.ndim == 4:
-                pass   # the reference also returns a 5-D (T = 1) reconstruction for image input
+            recon = self._recon_out(plan)      # image input: the reference also returns a 5-D (T = 1) reconstruction
             if return_codes:
                 codes = self._ids_out(plan)
                 return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
             if return_recon_loss_only:
-                if plan.sep:
-                    raise NotImplementedError('return_recon_loss_only with separate_first_frame_encoding is not built')
-                plan.run(plan.loss_steps[:1])
-                return plan.sq_sum[0] / plan.video_in.numel(), recon
+                plan.run(plan.loss_steps[:plan.n_recon_steps])
+                return self._recon_loss(plan), recon
             return recon
 
-    def _forward_discr_loss(self, video, cond=None):
+    @staticmethod
+    def _pick_frames(video, frame_indices):
+        """pick_video_frame (reference :88-97): one frame per sample"""
+        bi = torch.arange(video.shape[0], device=video.device)
+        return video[bi, :, frame_indices[:, 0].to(video.device)]
+
+    def _discr_logits(self, plan: Plan, images):
+        if self.discr._ops is None and getattr(plan.ops, 'name', '') != 'hip':
+            self.discr._set_backend(plan.ops)                     # test hook: the emulation backend serves both modules
+        self.discr.compute_dtype = plan.dtype
+        return self.discr(images)
+
+    def _forward_discr_loss(self, video, cond=None, vcff=True):
         """forward(return_discr_loss=True, apply_gradient_penalty=False) (reference M:1730-1782): a random frame per sample of the
-        clip and of its reconstruction through the image discriminator, hinge loss of the two logit vectors."""
-        plan, key = self._plan(video.shape[0], video.shape[2])
+        clip and of its reconstruction through the image discriminator, hinge loss of the two logit vectors; every multiscale
+        discriminator (a caller-supplied torch module on whole clips, M:1756-1763) adds the hinge loss of its own logits."""
+        plan, key = self._plan(video.shape[0], video.shape[2], headless=not vcff)
         self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
         self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
         recon = self._recon_out(plan)
         batch, frames = video.shape[0], video.shape[2]
-        frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices.to(video.device)      # CPU generator, as the reference (:1736)
-        bi = torch.arange(batch, device=video.device)
-        real = video[bi, :, frame_indices[:, 0]].float()
-        fake = recon[bi, :, frame_indices[:, 0]]
-        if self.discr._ops is None and getattr(plan.ops, 'name', '') != 'hip':
-            self.discr._set_backend(plan.ops)                     # test hook: the emulation backend serves both modules
-        self.discr.compute_dtype = plan.dtype
-        real_logits, fake_logits = self.discr(real), self.discr(fake)
-        out = plan.ops.empty((1,), torch.float32)
-        plan.run([plan.ops.hinge_discr_loss(fake_logits, real_logits, batch, out)])
-        discr_loss = out[0].clone()
-        zero = torch.zeros((), device=discr_loss.device)
-        return discr_loss, DiscrLossBreakdown(discr_loss, [zero], zero)
+        frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices      # CPU generator, as the reference (:1736)
+        real_logits = self._discr_logits(plan, self._pick_frames(video, frame_indices).float())
+        fake_logits = self._discr_logits(plan, self._pick_frames(recon, frame_indices))
 
-    def _forward_loss(self, video, cond=None):
-        """forward(return_loss=True) (reference M:1705-1722, 1785-1817 with use_gan=False, no perceptual loss): forward values only
-        (this build has no backward).  Training mode + LFQ: the quantizer runs its straight-through forward value and the
+        def hinge(fake, real):
+            out = plan.ops.empty((1,), torch.float32)
+            fake, real = fake.reshape(-1).float().contiguous(), real.reshape(-1).float().contiguous()
+            plan.run([plan.ops.hinge_discr_loss(fake, real, fake.numel(), out)])
+            return out[0].clone()
+
+        discr_loss = hinge(fake_logits, real_logits)
+        zero = torch.zeros((), device=discr_loss.device)
+        ms = [zero]
+        if self.has_multiscale_discrs:
+            vin = video.float()
+            ms = [hinge(d(recon), d(vin)) for d in self.multiscale_discrs]
+        total = discr_loss + sum(ms) * self.multiscale_adversarial_loss_weight      # gradient penalty: zero (:1769-1778)
+        return total, DiscrLossBreakdown(discr_loss, ms, zero)
+
+    def _forward_loss(self, video, cond=None, vcff=True, adversarial_loss_weight=1., multiscale_adversarial_loss_weight=1.):
+        """forward(return_loss=True) (reference M:1705-1722, 1785-1896): forward values only (this build has no backward).
+        Training mode + LFQ: the quantizer runs its straight-through forward value and the
         entropy / commitment auxiliary loss (third-party LFQ.forward, training branch) from on-device statistics, all-reduced
         over the default process group when one is initialised (the third-party code all-reduces the mean code distribution; here
         every token-sum travels, so each rank reports the GLOBAL-batch auxiliary loss).  The reconstruction loss stays per
-        rank, as in the reference."""
-        if self.separate_first_frame_encoding:
-            raise NotImplementedError('forward(return_loss=True) with separate_first_frame_encoding is not built (the loss kernels read one recon buffer)')
+        rank, as in the reference.  With a GAN: -mean(D(one random reconstructed frame per sample)) through the image
+        discriminator's kernels (M:1826-1832), adaptive weight 1.  Perceptual term: the caller's `vgg` module on one random frame
+        pair per sample (M:1785-1805), drawn first, as in the reference."""
         train = self.training and not self.use_fsq
         if train and self.cfg['codebook_size'] > 4096:
             raise NotImplementedError('the training-mode entropy loss enumerates the codebook per token; mv2_lfq_stats supports '
                                       'codebook_size <= 4096 per codebook (use eval mode, or more codebooks of <= 12 bits)')
-        plan, key = self._plan(video.shape[0], video.shape[2], train=train)
+        plan, key = self._plan(video.shape[0], video.shape[2], train=train, headless=not vcff)
         self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
         self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
-        recon_loss = plan.sq_sum[0] / plan.video_in.numel()
+        recon_loss = self._recon_loss(plan)
         zero = torch.zeros((), device=recon_loss.device)
         if train:
             n_tokens = plan.n_tokens
@@ -520,4 +563,33 @@ class VideoTokenizer(nn.Module):
         else:
             aux, breakdown = zero, QuantizerLossBreakdown(zero, zero, zero)       # eval mode / FSQ: aux loss is zero (M:1705-1709)
         total = recon_loss + aux * self.quantizer_aux_loss_weight
-        return total, LossBreakdown(recon_loss, aux, breakdown, zero, zero, 0., [], [])
+        perceptual, gen_loss, adaptive_weight, ms_losses, ms_weights = zero, zero, 0., [], []
+        if not (self.use_vgg or self.has_gan or self.has_multiscale_discrs):
+            return total, LossBreakdown(recon_loss, aux, breakdown, zero, zero, 0., [], [])
+        recon = self._recon_out(plan)
+        batch, frames = video.shape[0], video.shape[2]
+        frame_indices, picked = None, None
+        if self.use_vgg:                                                          # M:1785-1805
+            frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices
+            a, b = self._pick_frames(video, frame_indices).float(), self._pick_frames(recon, frame_indices)
+            if self.channels == 1:
+                a, b = a.expand(-1, 3, -1, -1), b.expand(-1, 3, -1, -1)
+            elif self.channels == 4:
+                a, b = a[:, :3], b[:, :3]
+            perceptual = torch.nn.functional.mse_loss(self.vgg(a), self.vgg(b))
+        if self.has_gan:                                                          # M:1826-1832: hinge_gen_loss = -mean(fake logits)
+            frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices
+            picked = self._pick_frames(recon, frame_indices)
+            gen_loss, adaptive_weight = -self._discr_logits(plan, picked).mean(), 1.
+        if self.has_multiscale_gan and self.has_multiscale_discrs:                # M:1851-1869
+            if picked is None:
+                if frame_indices is None:
+                    raise NameError('the reference reads `frame_indices` before assignment on this branch (M:1853) unless has_gan or use_vgg')
+                picked = self._pick_frames(recon, frame_indices)
+            # the reference takes the picked frames themselves as the "logits" (M:1856: `fake_logits = recon_video_frames`)
+            ms_losses = [-picked.mean() for _ in self.multiscale_discrs]
+            ms_weights = [1. for _ in self.multiscale_discrs]
+        total = total + perceptual * self.perceptual_loss_weight + gen_loss * adaptive_weight * adversarial_loss_weight
+        if self.has_multiscale_discrs:
+            total = total + sum(l * w for l, w in zip(ms_losses, ms_weights)) * multiscale_adversarial_loss_weight
+        return total, LossBreakdown(recon_loss, aux, breakdown, perceptual, gen_loss, adaptive_weight, ms_losses, ms_weights)

@@ -66,6 +66,29 @@ def make_input(shape, seed):
     return torch.randn(*shape, generator=g)
 
 
+class ClipDiscr(torch.nn.Module):
+    """a stand-in for a caller-supplied multiscale discriminator (reference M:1085, 1433): any module mapping a clip
+    (B, C, T, H, W) to logits.  Module-level so the reference's config pickling (M:1097-1100) accepts it; seeded weights."""
+
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w = torch.nn.Parameter(torch.randn(4, 3, 2, 4, 4, generator=g) * 0.2)
+
+    def forward(self, x):
+        return torch.nn.functional.conv3d(x, self.w.to(x.dtype), stride=(1, 4, 4)).flatten(1).mean(dim=1)
+
+
+def tiny_vgg(seed):
+    """a stand-in for a caller-supplied `vgg` feature extractor (reference M:1081, 1397-1405), seeded"""
+    g = torch.Generator().manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=2), torch.nn.ReLU(), torch.nn.Flatten())
+    with torch.no_grad():
+        net[0].weight.copy_(torch.randn(4, 3, 3, 3, generator=g) * 0.3)
+        net[0].bias.copy_(torch.randn(4, generator=g) * 0.1)
+    return net.eval()
+
+
 def generate(name):
     kw, shape, wseed, dseed, stride = CASES[name]
     cfg = make_cfg(**kw)
@@ -128,6 +151,21 @@ FEATURES = {
                                  shape=(2, 3, 9, 16, 16), wseed=4, dseed=1),
     'feat_discr': dict(kw=dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual')),
                        shape=(3, 3, 5, 16, 16), wseed=5, dseed=6, discr_seed=9, pick_seed=77),
+    # video_contains_first_frame=False (headless clips, M:1530-1538, 1646, 1691), with and without separate_first_frame_encoding
+    'feat_headless': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64,
+                                  layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
+                          shape=(2, 3, 8, 16, 16), wseed=21, dseed=22),
+    'feat_headless_sep': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+                                      layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
+                              shape=(2, 3, 8, 16, 16), wseed=21, dseed=22),
+    # forward(return_loss=True) with a GAN, a caller-supplied VGG and two multiscale discriminators (M:1785-1896, forward values),
+    # the discriminator branch with the multiscale terms (M:1752-1782), and the losses with separate_first_frame_encoding
+    'feat_gan_loss': dict(kw=dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual')),
+                          shape=(3, 3, 5, 16, 16), wseed=5, dseed=6, discr_seed=9, pick_seed=78, ms_seeds=(1, 2), vgg_seed=3,
+                          adversarial_loss_weight=0.7, multiscale_adversarial_loss_weight=0.5, perceptual_loss_weight=0.3),
+    'feat_sep_loss': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+                                  layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
+                          shape=(2, 3, 9, 16, 16), wseed=4, dseed=1),
 }
 
 
@@ -159,6 +197,53 @@ def generate_feature(name):
             out.update({f'{mode}_total': f32(total), f'{mode}_recon': f32(br.recon_loss), f'{mode}_aux': f32(torch.as_tensor(br.lfq_aux_loss)),
                         f'{mode}_per_sample_entropy': f32(torch.as_tensor(qb.per_sample_entropy)),
                         f'{mode}_batch_entropy': f32(torch.as_tensor(qb.batch_entropy)), f'{mode}_commitment': f32(torch.as_tensor(qb.commitment))})
+    elif name.startswith('feat_headless'):
+        ref = make_reference_tokenizer(**kw)
+        ref.load_state_dict(sd, strict=False)
+        with torch.no_grad():
+            codes, recon = ref(video, return_codes=True, return_recon=True, video_contains_first_frame=False)
+            dec = ref.decode_from_code_indices(codes, video_contains_first_frame=False)
+        assert torch.equal(dec, recon) and recon.shape == video.shape
+        out.update(codes=codes.numpy(), recon=recon.numpy().astype(np.float32))
+    elif name == 'feat_sep_loss':
+        ref = make_reference_tokenizer(**kw)
+        ref.load_state_dict(sd, strict=False)
+        for mode in ('train', 'eval'):
+            ref.train(mode == 'train')
+            with torch.no_grad():
+                total, br = ref(video, return_loss=True)
+                rl, _ = ref(video, return_recon_loss_only=True)
+            assert float(rl) == float(br.recon_loss)
+            out.update({f'{mode}_total': f32(total), f'{mode}_recon': f32(br.recon_loss), f'{mode}_aux': f32(torch.as_tensor(br.lfq_aux_loss))})
+    elif name == 'feat_gan_loss':
+        dsd = discr_state_dict(16, kw['image_size'], f['discr_seed'])
+        out.update(discr_sha256=weights_sha(dsd))
+        wts = dict(adversarial_loss_weight=f['adversarial_loss_weight'], multiscale_adversarial_loss_weight=f['multiscale_adversarial_loss_weight'])
+        # (a) GAN only, train and eval mode
+        ref = make_reference_tokenizer(**kw, use_gan=True, adversarial_loss_weight=f['adversarial_loss_weight'])
+        missing, unexpected = ref.load_state_dict({**sd, **dsd}, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        for mode in ('train', 'eval'):
+            ref.train(mode == 'train')
+            torch.manual_seed(f['pick_seed'])
+            with torch.no_grad():
+                total, br = ref(video, return_loss=True)
+            assert br.adaptive_adversarial_weight == 1.
+            out.update({f'gan_{mode}_total': f32(total), f'gan_{mode}_gen': f32(br.adversarial_gen_loss), f'gan_{mode}_recon': f32(br.recon_loss)})
+        # (b) GAN + caller-supplied VGG + two multiscale discriminators, eval mode: generator branch and discriminator branch
+        ms = tuple(ClipDiscr(sd_) for sd_ in f['ms_seeds'])
+        ref = make_reference_tokenizer(**kw, use_gan=True, vgg=tiny_vgg(f['vgg_seed']), perceptual_loss_weight=f['perceptual_loss_weight'],
+                                       multiscale_discrs=ms, **wts)
+        ref.load_state_dict({**sd, **dsd}, strict=False)
+        torch.manual_seed(f['pick_seed'] + 1)
+        with torch.no_grad():
+            total, br = ref(video, return_loss=True)
+        out.update(full_total=f32(total), full_perceptual=f32(br.perceptual_loss), full_gen=f32(br.adversarial_gen_loss),
+                   full_ms_gen=np.array([float(x) for x in br.multiscale_gen_losses]))
+        torch.manual_seed(f['pick_seed'] + 2)
+        with torch.no_grad():
+            total, br = ref(video, return_discr_loss=True, apply_gradient_penalty=False)
+        out.update(full_discr_total=f32(total), full_discr=f32(br.discr_loss), full_ms_discr=np.array([float(x) for x in br.multiscale_discr_losses]))
     elif name == 'feat_discr':
         ref = make_reference_tokenizer(**kw, use_gan=True)
         dsd = discr_state_dict(16, kw['image_size'], f['discr_seed'])

@@ -401,11 +401,13 @@ class OracleTokenizer:
             return feed_forward(token_shift(x), p, pre + '.1.fn.fn.') + x
         raise ValueError(kind)
 
-    def encode(self, video, cond=None):
-        """M:1522-1576 (video_contains_first_frame=True, no separate first frame).
-        NB the trailing LayerNorm of encoder_layers is never executed (zip truncation, M:1565)."""
+    def encode(self, video, cond=None, video_contains_first_frame=True):
+        """M:1522-1576.  NB the trailing LayerNorm of encoder_layers is never executed (zip truncation, M:1565).
+        video_contains_first_frame=False ("headless" clips, M:1530-1538): no time_padding zero frames in front and the first
+        frame is not treated separately; conv_in still pads causally on its own."""
         x = video.to(self.dtype)
-        if self.separate_first_frame:
+        tp = self.time_padding if video_contains_first_frame else 0
+        if self.separate_first_frame and video_contains_first_frame:
             # M:1553-1561: first frame through its own SameConv2d, the REMAINING frames through conv_in (whose causal zero
             # padding starts right before frame 1 — it never sees the first frame), then time_padding zero frames in front
             w2 = self.p['conv_in_first_frame.weight']
@@ -414,7 +416,7 @@ class OracleTokenizer:
             x = torch.cat((ff.unsqueeze(2), rest), dim=2)
             x = self._tap('conv_in', F.pad(x, (0, 0, 0, 0, self.time_padding, 0)))
         else:
-            x = F.pad(x, (0, 0, 0, 0, self.time_padding, 0))                    # M:1537
+            x = F.pad(x, (0, 0, 0, 0, tp, 0))                                   # M:1534-1537
             x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
         ce = self._cond_in(cond, 'encoder_cond_in')
         for i, st in enumerate(self.stages):
@@ -434,64 +436,74 @@ class OracleTokenizer:
             return fsq_indices_to_codes(ids, self.p, self.fsq_levels)
         return lfq_indices_to_codes(ids, self.p, self.codebook_dim, self.num_codebooks)
 
-    def decode(self, q, cond=None):
-        """M:1597-1649."""
+    def decode(self, q, cond=None, video_contains_first_frame=True):
+        """M:1597-1649 (headless: nothing is cropped, M:1646)."""
         x = q
         n = len(self.stages)
         cd = self._cond_in(cond, 'decoder_cond_in')
         for j, st in enumerate(reversed(self.stages)):
             x = self._tap(f'dec{j}', self._stage(x, st, f'decoder_layers.{j}', False, cond=cd))
-        if self.separate_first_frame:                                            # M:1633-1639
+        if self.separate_first_frame and video_contains_first_frame:             # M:1633-1639
             tp = self.time_padding
             w2 = self.p['conv_out_first_frame.weight']
             outff = F.conv2d(x[:, :, tp], w2, self.p['conv_out_first_frame.bias'], padding=(w2.shape[-2] // 2, w2.shape[-1] // 2))
             out = causal_conv3d(x[:, :, tp + 1:], self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
             return torch.cat((outff.unsqueeze(2), out), dim=2)
         x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
-        return x[:, :, self.time_padding:]                                       # M:1646-1647
+        return x[:, :, self.time_padding:] if video_contains_first_frame else x  # M:1646-1647
 
-    def decode_from_code_indices(self, codes, cond=None):
+    def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):
         """M:1578-1595."""
         assert codes.dtype in (torch.long, torch.int32)
         if codes.ndim == 2:
             f2 = self.fmap_size ** 2
             assert codes.shape[-1] % f2 == 0
             codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
-        return self.decode(self.indices_to_codes(codes), cond=cond)
+        return self.decode(self.indices_to_codes(codes), cond=cond, video_contains_first_frame=video_contains_first_frame)
 
     def tokenize(self, video, cond=None):
         return self.forward(video, cond=cond, return_codes=True)
 
-    def forward(self, video, cond=None, return_codes=False, return_recon=False):
+    def forward(self, video, cond=None, return_codes=False, return_recon=False, video_contains_first_frame=True):
         """M:1656-1720 eval branches."""
         assert video.ndim in (4, 5)
         assert video.shape[-2:] == (self.image_size, self.image_size)
         if video.ndim == 4:
-            video = video.unsqueeze(2)
-        assert (video.shape[2] - 1) % self.time_downsample_factor == 0
+            video, video_contains_first_frame = video.unsqueeze(2), True        # M:1683-1685
+        vcff = video_contains_first_frame
+        assert (video.shape[2] - int(vcff)) % self.time_downsample_factor == 0   # M:1691
         with torch.no_grad():
-            x = self.encode(video, cond=cond)
+            x = self.encode(video, cond=cond, video_contains_first_frame=vcff)
             q, ids = self.quantize(x)
             if return_codes and not return_recon:
                 return ids
-            recon = self.decode(q, cond=cond)
+            recon = self.decode(q, cond=cond, video_contains_first_frame=vcff)
         if return_codes:
             return ids, recon
         return recon
 
     def forward_loss(self, video, training=True, lfq_entropy_loss_weight=0.1, lfq_commitment_loss_weight=1., lfq_diversity_gamma=2.5,
-                     quantizer_aux_loss_weight=1.):
-        """M:1656-1896 with return_loss=True, no GAN, no perceptual loss (use_gan=False, perceptual_loss_weight=0):
-        total = mse(video, recon) + aux * quantizer_aux_loss_weight; aux = 0 in eval mode and for FSQ (M:1700-1705).
-        Returns (total, dict(recon_loss, aux, per_sample_entropy, batch_entropy, commitment))."""
+                     quantizer_aux_loss_weight=1., cond=None, video_contains_first_frame=True, discr_params=None, discr_kw=None,
+                     adversarial_loss_weight=1., multiscale_discrs=(), multiscale_adversarial_loss_weight=1., vgg=None,
+                     perceptual_loss_weight=0.):
+        """M:1656-1896 with return_loss=True: total = mse(video, recon) + aux * quantizer_aux_loss_weight
+        (+ perceptual * w + gen_loss * adaptive_weight * adversarial_loss_weight + multiscale terms); aux = 0 in eval mode and
+        for FSQ (M:1700-1705).  Forward values only, so the adaptive weights are the constant 1 of M:1832 / 1861 (the
+        gradient-norm ratio of M:1819-1842 exists only in training mode WITH a VGG).
+        discr_params: the `discr.*` entries -> the generator's hinge loss -mean(D(random recon frame)) (M:1826-1832);
+        multiscale_discrs: only their NUMBER matters to the reference, which never calls them on this branch (M:1856:
+        `fake_logits = recon_video_frames`), so each contributes -mean(picked recon frames);
+        vgg: a callable on (B, 3, H, W) frames (M:1785-1805), eval mode only.
+        Returns (total, dict(recon_loss, aux, per_sample_entropy, batch_entropy, commitment, perceptual, gen_loss, multiscale_gen_losses))."""
         if video.ndim == 4:
-            video = video.unsqueeze(2)
+            video, video_contains_first_frame = video.unsqueeze(2), True
+        vcff = video_contains_first_frame
         with torch.no_grad():
-            x = self.encode(video)
+            x = self.encode(video, cond=cond, video_contains_first_frame=vcff)
             train = training and not self.use_fsq
             self.taps = self.taps if self.taps is not None else {}
             q, ids = self.quantize(x, train=train)
-            recon = self.decode(q)
+            recon = self.decode(q, cond=cond, video_contains_first_frame=vcff)
             recon_loss = F.mse_loss(video, recon)
             zero = recon_loss.new_zeros(())
             if train:
@@ -499,17 +511,50 @@ class OracleTokenizer:
                                                    entropy_loss_weight=lfq_entropy_loss_weight, commitment_loss_weight=lfq_commitment_loss_weight)
             else:
                 ps = bt = cm = aux = zero
-        total = recon_loss + aux * quantizer_aux_loss_weight
-        return total, dict(recon_loss=recon_loss, aux=aux, per_sample_entropy=ps, batch_entropy=bt, commitment=cm)
+            batch, frames = video.shape[0], video.shape[2]
+            bi = torch.arange(batch)
+            pick = lambda vid, idx: vid[bi, :, idx[:, 0]]                                    # pick_video_frame M:88-97
+            perceptual, fi = zero, None
+            if vgg is not None and perceptual_loss_weight > 0.:                              # M:1785-1805
+                assert not training, 'training mode + VGG needs the gradient-norm adaptive weight (autograd)'
+                fi = torch.randn((batch, frames)).topk(1, dim=-1).indices
+                a, b = pick(video, fi), pick(recon, fi)
+                if self.channels == 1:
+                    a, b = a.expand(-1, 3, -1, -1), b.expand(-1, 3, -1, -1)
+                elif self.channels == 4:
+                    a, b = a[:, :3], b[:, :3]
+                perceptual = F.mse_loss(vgg(a), vgg(b))
+            gen_loss, frames_picked = zero, None
+            has_gan = discr_params is not None and adversarial_loss_weight > 0.
+            if has_gan:                                                                      # M:1826-1832
+                fi = torch.randn((batch, frames)).topk(1, dim=-1).indices
+                frames_picked = pick(recon, fi)
+                kw = dict(dict(image_size=self.image_size, channels=self.channels), **(discr_kw or {}))
+                gen_loss = -discriminator_forward(frames_picked, discr_params, 'discr.', **kw).mean()      # hinge_gen_loss M:123-124
+            ms = []
+            if len(multiscale_discrs) > 0 and multiscale_adversarial_loss_weight > 0.:      # M:1851-1869
+                if frames_picked is None and fi is not None:
+                    frames_picked = pick(recon, fi)
+                if frames_picked is None:
+                    raise NameError('the reference reads `frame_indices` before assignment here (M:1853) unless has_gan or use_vgg')
+                ms = [-frames_picked.mean() for _ in multiscale_discrs]
+        total = recon_loss + aux * quantizer_aux_loss_weight + perceptual * perceptual_loss_weight + gen_loss * adversarial_loss_weight
+        if ms:
+            total = total + sum(ms) * multiscale_adversarial_loss_weight
+        return total, dict(recon_loss=recon_loss, aux=aux, per_sample_entropy=ps, batch_entropy=bt, commitment=cm,
+                           perceptual=perceptual, gen_loss=gen_loss, multiscale_gen_losses=ms)
 
-    def forward_discr_loss(self, video, discr_params, *, dim, channels=3, max_dim=512, cond=None):
-        """M:1730-1782 with apply_gradient_penalty=False and no multiscale discriminators: one random frame per sample
+    def forward_discr_loss(self, video, discr_params, *, dim, channels=3, max_dim=512, cond=None, video_contains_first_frame=True,
+                           multiscale_discrs=(), multiscale_adversarial_loss_weight=1.):
+        """M:1730-1782 with apply_gradient_penalty=False: one random frame per sample
         (torch.randn((batch, frames)).topk(1) on the CPU default generator — seed it before the call to compare), real and
-        reconstructed frame through the image discriminator, hinge loss.  discr_params: the `discr.*` entries."""
+        reconstructed frame through the image discriminator, hinge loss; every multiscale discriminator (any callable on the
+        whole clip, M:1756-1763) adds hinge(D(recon), D(video)) * multiscale_adversarial_loss_weight.
+        discr_params: the `discr.*` entries.  Returns (total, real_logits, fake_logits)."""
         if video.ndim == 4:
-            video = video.unsqueeze(2)
+            video, video_contains_first_frame = video.unsqueeze(2), True
         with torch.no_grad():
-            recon = self.forward(video, cond=cond, return_recon=True)
+            recon = self.forward(video, cond=cond, return_recon=True, video_contains_first_frame=video_contains_first_frame)
             batch, frames = video.shape[0], video.shape[2]
             frame_indices = torch.randn((batch, frames)).topk(1, dim=-1).indices
             bi = torch.arange(batch)
@@ -517,7 +562,11 @@ class OracleTokenizer:
             kw = dict(dim=dim, image_size=self.image_size, channels=channels, max_dim=max_dim)
             real_logits = discriminator_forward(real, discr_params, 'discr.', **kw)
             fake_logits = discriminator_forward(fake, discr_params, 'discr.', **kw)
-        return hinge_discr_loss(fake_logits, real_logits), real_logits, fake_logits
+            total = hinge_discr_loss(fake_logits, real_logits)
+            if multiscale_adversarial_loss_weight > 0.:
+                for d in multiscale_discrs:
+                    total = total + hinge_discr_loss(d(recon), d(video)) * multiscale_adversarial_loss_weight
+        return total, real_logits, fake_logits
 
     __call__ = forward
 

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
-from oracle.make_golden import make_input, sha_tensors, weights_sha
+from oracle.make_golden import ClipDiscr, make_input, sha_tensors, tiny_vgg, weights_sha   # noqa: F401
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -79,3 +79,7 @@ class Feature:
 
     def scalar(self, key):
         return float(self.z[key])
+
+    def discr_dim(self):
+        return self.f.get('discr_dim', 16)
+

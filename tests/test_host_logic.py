@@ -521,3 +521,174 @@ def test_facade_vs_reference_feature_fixtures():
     torch.manual_seed(f.f['pick_seed'])
     total, _ = tok(f.video(), return_discr_loss=True, apply_gradient_penalty=False)
     assert abs(float(total) - f.scalar('discr_loss')) <= 1e-5
+
+
+# ------------------------------------------------------------------------------- headless clips, GAN-side loss terms, multiscale discriminators
+SEP_KW = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+GAN_KW = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+
+
+@pytest.mark.parametrize('sep', [False, True])
+def test_headless_video_matches_oracle(sep):
+    """video_contains_first_frame=False on every method (reference M:1530-1538, 1604, 1646, 1691): a plan without the
+    time_padding zero frames and without the output crop; separate_first_frame_encoding does not apply to such clips."""
+    kw = dict(SEP_KW, separate_first_frame_encoding=sep)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=21, randomize_se=True)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    orc = OracleTokenizer(sd, **cfg)
+    v = torch.randn(2, 3, 8, 16, 16, generator=torch.Generator().manual_seed(22))
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=False)
+    codes, recon = tok(v, return_codes=True, return_recon=True, video_contains_first_frame=False)
+    assert codes.shape == (2, 2, 8, 8) and torch.equal(codes, ocodes) and (recon - orecon).abs().max().item() <= 5e-6
+    assert (tok.decode_from_code_indices(ocodes, video_contains_first_frame=False) - orecon).abs().max().item() <= 5e-6
+    assert (tok.decode_from_code_indices(ocodes.reshape(2, -1), video_contains_first_frame=False) - orecon).abs().max().item() <= 5e-6
+    q, ids, _ = tok.encode(v, quantize=True, video_contains_first_frame=False)
+    assert torch.equal(ids, ocodes) and (tok.decode(q, video_contains_first_frame=False) - orecon).abs().max().item() <= 5e-6
+    # the same tokenizer still serves clips WITH a first frame (separate plans per mode)
+    v9 = torch.randn(2, 3, 9, 16, 16, generator=torch.Generator().manual_seed(23))
+    c9, r9 = tok(v9, return_codes=True, return_recon=True)
+    oc9, or9 = orc(v9, return_codes=True, return_recon=True)
+    assert torch.equal(c9, oc9) and (r9 - or9).abs().max().item() <= 5e-6
+    with pytest.raises(AssertionError):
+        tok(v[:, :, :7], return_codes=True, video_contains_first_frame=False)          # 7 frames: not divisible by 4 (reference :1691)
+    with pytest.raises(AssertionError):
+        tok(v, return_codes=True)                                                      # 8 frames WITH a first frame: (8 - 1) % 4 != 0
+    img = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(24))
+    if not sep:      # an image always contains its first frame, whatever the flag says (reference :1681-1685)
+        assert torch.equal(tok(img, return_codes=True, video_contains_first_frame=False), orc(img, return_codes=True))
+
+
+@pytest.mark.parametrize('frames,vcff', [(9, True), (8, False)])
+def test_forward_loss_separate_first_frame_matches_oracle(frames, vcff):
+    kw = dict(SEP_KW, separate_first_frame_encoding=True)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=4, randomize_se=True)
+    tok = VideoTokenizer(**kw, use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok.load_state_dict(sd)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.train(True)
+    v = torch.randn(2, 3, frames, 16, 16, generator=torch.Generator().manual_seed(1))
+    want, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=True, video_contains_first_frame=vcff)
+    total, br = tok(v, return_loss=True, video_contains_first_frame=vcff)
+    assert abs(float(total) - float(want)) <= 1e-5 * max(1., abs(float(want)))
+    assert abs(float(br.recon_loss) - float(d['recon_loss'])) <= 2e-6
+    rl, recon = tok(v, return_recon_loss_only=True, video_contains_first_frame=vcff)
+    assert abs(float(rl) - float(d['recon_loss'])) <= 2e-6 and recon.shape == v.shape
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_forward_loss_with_gan_matches_oracle(training):
+    """use_gan=True, no VGG: total = recon + aux + adversarial_loss_weight * (-mean D(random reconstructed frame)) (reference M:1826-1832, 1872-1875)"""
+    cfg = make_cfg(**GAN_KW)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    tok = VideoTokenizer(**GAN_KW, use_gan=True, perceptual_loss_weight=0., adversarial_loss_weight=0.7, seed=0)
+    tok.load_state_dict(sd)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.train(training)
+    dsd = {k: v.clone() for k, v in tok.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(78)
+    total, br = tok(v, return_loss=True)
+    torch.manual_seed(78)
+    want, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=training, discr_params=dsd, discr_kw=dict(dim=16, max_dim=512), adversarial_loss_weight=0.7)
+    assert abs(float(total) - float(want)) <= 1e-5 * max(1., abs(float(want))), (float(total), float(want))
+    assert abs(float(br.adversarial_gen_loss) - float(d['gen_loss'])) <= 5e-6 and float(br.adversarial_gen_loss) != 0. and br.adaptive_adversarial_weight == 1.
+    torch.manual_seed(78)
+    total2, _ = tok(v, return_loss=True, adversarial_loss_weight=0.)                    # per-call override (reference :1671)
+    assert abs(float(total2) - (float(br.recon_loss) + float(br.lfq_aux_loss))) <= 2e-6
+
+
+def test_multiscale_discriminators_and_vgg_match_oracle():
+    from tests._util import ClipDiscr
+    cfg = make_cfg(**GAN_KW)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    ms = (ClipDiscr(1), ClipDiscr(2))
+    vgg = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=2), torch.nn.ReLU(), torch.nn.Flatten())
+    tok = VideoTokenizer(**GAN_KW, use_gan=True, vgg=vgg, perceptual_loss_weight=0.3, multiscale_discrs=ms, multiscale_adversarial_loss_weight=0.5, seed=0)
+    keys = set(tok.state_dict())
+    assert {'multiscale_discrs.0.w', 'multiscale_discrs.1.w', 'vgg.0.weight', 'vgg.0.bias'} <= keys       # the reference's key names for these modules
+    tok.load_state_dict(sd)                                                                                # tokenizer-only checkpoint: the caller's modules keep their weights
+    assert torch.equal(tok.multiscale_discrs[1].w, ms[1].w)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    tok.eval()
+    dsd = {k: v.clone() for k, v in tok.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    orc = OracleTokenizer(sd, **cfg)
+    torch.manual_seed(79)
+    total, br = tok(v, return_discr_loss=True, apply_gradient_penalty=False)
+    torch.manual_seed(79)
+    want, _, _ = orc.forward_discr_loss(v, dsd, dim=16, max_dim=512, multiscale_discrs=ms, multiscale_adversarial_loss_weight=0.5)
+    assert len(br.multiscale_discr_losses) == 2 and abs(float(total) - float(want)) <= 5e-6
+    torch.manual_seed(80)
+    total, br = tok(v, return_loss=True)
+    torch.manual_seed(80)
+    want, d = orc.forward_loss(v, training=False, discr_params=dsd, discr_kw=dict(dim=16, max_dim=512), multiscale_discrs=ms,
+                               multiscale_adversarial_loss_weight=0.5, vgg=vgg, perceptual_loss_weight=0.3)
+    assert abs(float(total) - float(want)) <= 1e-5 * max(1., abs(float(want))), (float(total), float(want))
+    assert abs(float(br.perceptual_loss) - float(d['perceptual'])) <= 5e-6 and float(br.perceptual_loss) > 0.
+    assert len(br.multiscale_gen_losses) == 2 and br.multiscale_gen_adaptive_weights == [1., 1.]
+    tok.train(True)
+    with pytest.raises(NotImplementedError):
+        tok(v, return_loss=True)                 # training + VGG + GAN: gradient-norm adaptive weights (autograd)
+
+
+def _widened_feature_checks(make_tok, to_dev, tol_total, tol_recon, ids_frac):
+    """shared by the CPU-emulation test below and its GPU twin (tests/test_zz_widen_gpu.py): the facade against the reference's own
+    outputs for headless clips, the GAN / VGG / multiscale loss terms and the losses under separate_first_frame_encoding."""
+    from oracle.make_golden import ClipDiscr, tiny_vgg
+    from tests._util import Feature
+    for name in ('feat_headless', 'feat_headless_sep'):
+        f = Feature(name)
+        tok = make_tok(dict(f.kw, use_gan=False), f.weights())
+        codes, recon = tok(to_dev(f.video()), return_codes=True, return_recon=True, video_contains_first_frame=False)
+        want = torch.from_numpy(f.z['codes'])
+        assert (codes.cpu() != want).float().mean().item() <= ids_frac, name
+        if torch.equal(codes.cpu(), want):
+            assert (recon.cpu() - torch.from_numpy(f.z['recon'])).abs().max().item() <= tol_recon, name
+        dec = tok.decode_from_code_indices(to_dev(want), video_contains_first_frame=False)
+        assert (dec.cpu() - torch.from_numpy(f.z['recon'])).abs().max().item() <= tol_recon, name
+    f = Feature('feat_gan_loss')
+    g = f.f
+    rel = lambda got, key: abs(float(got) - f.scalar(key)) <= tol_total * max(1., abs(f.scalar(key)))
+    tok = make_tok(dict(f.kw, use_gan=True, perceptual_loss_weight=0., adversarial_loss_weight=g['adversarial_loss_weight']), {**f.weights(), **f.discr_weights()})
+    for mode in ('train', 'eval'):
+        tok.train(mode == 'train')
+        torch.manual_seed(g['pick_seed'])
+        total, br = tok(to_dev(f.video()), return_loss=True)
+        assert rel(total, f'gan_{mode}_total') and rel(br.adversarial_gen_loss, f'gan_{mode}_gen') and rel(br.recon_loss, f'gan_{mode}_recon'), mode
+    ms = tuple(ClipDiscr(s) for s in g['ms_seeds'])
+    tok = make_tok(dict(f.kw, use_gan=True, vgg=tiny_vgg(g['vgg_seed']), perceptual_loss_weight=g['perceptual_loss_weight'], multiscale_discrs=ms,
+                        adversarial_loss_weight=g['adversarial_loss_weight'], multiscale_adversarial_loss_weight=g['multiscale_adversarial_loss_weight']),
+                   {**f.weights(), **f.discr_weights()})
+    tok.eval()
+    torch.manual_seed(g['pick_seed'] + 1)
+    total, br = tok(to_dev(f.video()), return_loss=True)
+    assert rel(total, 'full_total') and rel(br.perceptual_loss, 'full_perceptual') and rel(br.adversarial_gen_loss, 'full_gen')
+    assert all(abs(float(a) - float(b)) <= tol_total for a, b in zip(br.multiscale_gen_losses, f.z['full_ms_gen']))
+    torch.manual_seed(g['pick_seed'] + 2)
+    total, br = tok(to_dev(f.video()), return_discr_loss=True, apply_gradient_penalty=False)
+    assert rel(total, 'full_discr_total') and rel(br.discr_loss, 'full_discr')
+    assert all(abs(float(a) - float(b)) <= tol_total for a, b in zip(br.multiscale_discr_losses, f.z['full_ms_discr']))
+    f = Feature('feat_sep_loss')
+    tok = make_tok(dict(f.kw, use_gan=False, perceptual_loss_weight=0.), f.weights())
+    for mode in ('train', 'eval'):
+        tok.train(mode == 'train')
+        total, br = tok(to_dev(f.video()), return_loss=True)
+        assert abs(float(total) - f.scalar(f'{mode}_total')) <= tol_total * max(1., abs(f.scalar(f'{mode}_total'))), mode
+        rl, _ = tok(to_dev(f.video()), return_recon_loss_only=True)
+        assert abs(float(rl) - f.scalar(f'{mode}_recon')) <= tol_total * f.scalar(f'{mode}_recon')
+
+
+def test_facade_vs_reference_widened_feature_fixtures():
+    def make_tok(kw, sd):
+        tok = VideoTokenizer(**kw, seed=0)
+        tok.load_state_dict(sd)
+        tok._set_backend(CpuOps())
+        tok.compute_dtype = torch.float32
+        return tok
+    _widened_feature_checks(make_tok, lambda t: t, tol_total=1e-5, tol_recon=2e-5, ids_frac=0.)

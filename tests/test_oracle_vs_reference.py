@@ -194,3 +194,125 @@ def test_discr_loss_matches_reference():
     loss, _, _ = orc.forward_discr_loss(v, dsd, dim=16, max_dim=512)
     assert torch.allclose(loss, total, atol=2e-6) and torch.allclose(loss, br.discr_loss, atol=2e-6)
     assert float(br.gradient_penalty) == 0.
+
+
+# ------------------------------------------------------------------------------- headless clips (video_contains_first_frame=False)
+@pytest.mark.parametrize('sep', [False, True])
+def test_headless_video_matches_reference(sep):
+    """video_contains_first_frame=False (M:1530-1538, 1604, 1646, 1691): no time padding, no crop, the first frame is not special
+    even when separate_first_frame_encoding is configured; frame count divisible by the time downsample factor."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=sep,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=21, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 8, 16, 16, generator=torch.Generator().manual_seed(22))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True, video_contains_first_frame=False)
+        dec = ref.decode_from_code_indices(codes, video_contains_first_frame=False)
+    assert codes.shape == (2, 2, 8, 8) and recon.shape == v.shape
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=False)
+    assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes, video_contains_first_frame=False), dec, atol=1e-5, rtol=0)
+    with pytest.raises(AssertionError):
+        ref(v[:, :, :7], return_codes=True, video_contains_first_frame=False)      # 7 frames: not divisible by 4 (M:1691)
+    with pytest.raises(AssertionError):
+        orc(v[:, :, :7], return_codes=True, video_contains_first_frame=False)
+
+
+# ------------------------------------------------------------------------------- generator-side loss terms with a GAN (forward values)
+@pytest.mark.parametrize('training', [True, False])
+def test_forward_loss_with_gan_matches_reference(training):
+    """forward(return_loss=True) of the reference with use_gan=True and no VGG (M:1826-1832, 1872-1875): the generator's hinge loss
+    -mean(D(random reconstructed frame)) with adaptive weight 1, times adversarial_loss_weight."""
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    ref = make_reference_tokenizer(**kw, use_gan=True, adversarial_loss_weight=0.7)
+    ref.load_state_dict(sd, strict=False)
+    ref.train(training)
+    dsd = {k: v.clone() for k, v in ref.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(78)
+    with torch.no_grad():
+        total, br = ref(v, return_loss=True)
+    orc = OracleTokenizer(sd, **cfg)
+    torch.manual_seed(78)
+    ototal, d = orc.forward_loss(v, training=training, discr_params=dsd, discr_kw=dict(dim=16, max_dim=512), adversarial_loss_weight=0.7)
+    assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (float(ototal), float(total))
+    assert torch.allclose(d['gen_loss'], br.adversarial_gen_loss, atol=2e-6, rtol=1e-5) and float(d['gen_loss']) != 0.
+    assert br.adaptive_adversarial_weight == 1.
+    assert torch.allclose(d['recon_loss'], br.recon_loss, atol=2e-6, rtol=1e-5)
+
+
+def test_multiscale_discriminators_match_reference():
+    """multiscale_discrs are caller-supplied modules on whole clips: the discriminator branch adds hinge(D(recon), D(video)) per
+    module (M:1756-1763, 1776-1778); the generator branch never calls them — `fake_logits = recon_video_frames` (M:1856) — so
+    each adds -mean(picked reconstructed frames) with weight 1 (M:1857-1861, 1877-1881)."""
+    from tests._util import ClipDiscr
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    ms = (ClipDiscr(1), ClipDiscr(2))
+    ref = make_reference_tokenizer(**kw, use_gan=True, multiscale_discrs=ms, multiscale_adversarial_loss_weight=0.5)
+    ref.load_state_dict(sd, strict=False)
+    dsd = {k: v.clone() for k, v in ref.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    orc = OracleTokenizer(sd, **cfg)
+    torch.manual_seed(79)
+    with torch.no_grad():
+        total, br = ref(v, return_discr_loss=True, apply_gradient_penalty=False)
+    torch.manual_seed(79)
+    ototal, _, _ = orc.forward_discr_loss(v, dsd, dim=16, max_dim=512, multiscale_discrs=ms, multiscale_adversarial_loss_weight=0.5)
+    assert len(br.multiscale_discr_losses) == 2 and torch.allclose(ototal, total, atol=2e-6, rtol=1e-5)
+    torch.manual_seed(80)
+    with torch.no_grad():
+        total, br = ref(v, return_loss=True)
+    torch.manual_seed(80)
+    ototal, d = orc.forward_loss(v, training=False, discr_params=dsd, discr_kw=dict(dim=16, max_dim=512), multiscale_discrs=ms,
+                                 multiscale_adversarial_loss_weight=0.5)
+    assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (float(ototal), float(total))
+    assert len(br.multiscale_gen_losses) == 2 and br.multiscale_gen_adaptive_weights == [1., 1.]
+    assert torch.allclose(d['multiscale_gen_losses'][0], br.multiscale_gen_losses[0], atol=2e-6)
+
+
+def test_forward_loss_with_vgg_module_matches_reference():
+    """a caller-supplied `vgg` module (M:1397-1405, 1785-1805) in eval mode: perceptual = mse(vgg(frame), vgg(recon frame)) on one
+    random frame per sample, drawn BEFORE the discriminator's frame (two draws from the CPU generator)."""
+    vgg = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=2), torch.nn.ReLU(), torch.nn.Flatten())
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    ref = make_reference_tokenizer(**kw, use_gan=True, vgg=vgg, perceptual_loss_weight=0.3)
+    ref.load_state_dict(sd, strict=False)
+    dsd = {k: v.clone() for k, v in ref.state_dict().items() if k.startswith('discr.')}
+    v = torch.randn(3, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(81)
+    with torch.no_grad():
+        total, br = ref(v, return_loss=True)
+    torch.manual_seed(81)
+    ototal, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=False, discr_params=dsd, discr_kw=dict(dim=16, max_dim=512), vgg=vgg,
+                                                        perceptual_loss_weight=0.3)
+    assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (float(ototal), float(total))
+    assert torch.allclose(d['perceptual'], br.perceptual_loss, atol=2e-6, rtol=1e-5) and float(d['perceptual']) > 0.
+
+
+def test_forward_loss_separate_first_frame_and_headless_match_reference():
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=4, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    ref.train(True)
+    orc = OracleTokenizer(sd, **cfg)
+    for frames, vcff in ((9, True), (8, False)):
+        v = torch.randn(2, 3, frames, 16, 16, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            total, br = ref(v, return_loss=True, video_contains_first_frame=vcff)
+            rl, rv = ref(v, return_recon_loss_only=True, video_contains_first_frame=vcff)
+        ototal, d = orc.forward_loss(v, training=True, video_contains_first_frame=vcff)
+        assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (frames, float(ototal), float(total))
+        assert torch.allclose(d['recon_loss'], rl, atol=2e-6, rtol=1e-5)

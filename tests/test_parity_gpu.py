@@ -65,7 +65,7 @@ def margin_check(codes, ref_codes, prequant_ref, tau, max_frac):
 
 
 # ------------------------------------------------------------------------------- lockstep: every launch
-def run_lockstep(cfg, sd, v, dtype, cond=None):
+def run_lockstep(cfg, sd, v, dtype, cond=None, headless=False):
     """Builds the same plan for the HIP backend and for the CPU emulation of the kernel semantics,
     runs them launch by launch and compares every output buffer of every launch (teacher-forced, so a
     failure names the first wrong kernel)."""
@@ -73,8 +73,8 @@ def run_lockstep(cfg, sd, v, dtype, cond=None):
     v = v.unsqueeze(2) if v.ndim == 4 else v
     B, T = v.shape[0], v.shape[2]
     hops, cops = HipOps('cuda:0'), CpuOps()
-    ph = Plan(PackedModel(cfg, sd, dtype, hops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
-    pc = Plan(PackedModel(cfg, sd, dtype, cops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True)
+    ph = Plan(PackedModel(cfg, sd, dtype, hops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True, headless=headless)
+    pc = Plan(PackedModel(cfg, sd, dtype, cops), B, T, cfg['image_size'], cfg['image_size'], want_prequant=True, headless=headless)
     ph.video_in.copy_(v); pc.video_in.copy_(v)
     if ph.sep:
         for pl in (ph, pc):
