@@ -216,20 +216,56 @@ class VideoTokenizer(nn.Module):
         return self.zero.device
 
     def state_dict(self, *args, **kwargs):
-        return super().state_dict(*args, **kwargs)
+        """as the reference (@remove_vgg, :141-155, 1486-1488): the perceptual network is never part of a checkpoint"""
+        vgg = self._modules.pop('vgg', None)
+        try:
+            return super().state_dict(*args, **kwargs)
+        finally:
+            if vgg is not None:
+                self._modules['vgg'] = vgg
+
+    def parameters(self, recurse=True):
+        """the tokenizer's own parameters only — no discriminator, VGG or multiscale discriminators (reference :1459-1470)"""
+        skip = ('discr.', 'vgg.', 'multiscale_discrs.')
+        return [p for n, p in self.named_parameters(recurse=recurse) if not n.startswith(skip)]
+
+    def discr_parameters(self):
+        return self.discr.parameters()                           # reference :1472-1473
+
+    def copy_for_eval(self):
+        """deep copy without discriminator / VGG / multiscale discriminators, in eval mode, on the same device (reference
+        :1475-1484).  Packed weights, plans and graphs are per-instance caches and are rebuilt by the copy on first use."""
+        import copy
+        ops, self._ops = self._ops, None
+        self.refresh_weights()
+        try:
+            dup = copy.deepcopy(self)
+        finally:
+            self._ops = ops
+        dup._modules.pop('discr', None)
+        dup._modules.pop('vgg', None)
+        dup.discr, dup.vgg = None, None
+        dup.multiscale_discrs = nn.ModuleList([])
+        dup.use_gan = dup.has_gan = dup.has_multiscale_gan = dup.has_multiscale_discrs = dup.use_vgg = False
+        dup.eval()
+        return dup
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """Accepts a reference state_dict unchanged: discriminator / VGG entries are ignored."""
         has_discr = self.discr is not None and any(k.startswith('discr.') for k in state_dict)
-        drop = lambda k: ((k.startswith('discr.') and not has_discr) or (k.startswith('vgg.') and self.vgg is None)
+        drop = lambda k: ((k.startswith('discr.') and not has_discr) or k.startswith('vgg.')
                           or (k.startswith('multiscale_discrs.') and len(self.multiscale_discrs) == 0))
         sd = {k: v for k, v in state_dict.items() if not drop(k)}
         if self.discr is not None and not has_discr:          # tokenizer-only checkpoint: the discriminator keeps its weights
             sd.update({'discr.' + k: v for k, v in self.discr.state_dict().items()})
-        for name, mod in (('vgg', self.vgg), ('multiscale_discrs', self.multiscale_discrs)):       # likewise the caller's modules
-            if isinstance(mod, nn.Module) and not any(k.startswith(name + '.') for k in state_dict):
-                sd.update({f'{name}.{k}': v for k, v in mod.state_dict().items()})
-        out = super().load_state_dict(sd, strict=strict, **kw)
+        if len(self.multiscale_discrs) and not any(k.startswith('multiscale_discrs.') for k in state_dict):       # likewise the caller's modules
+            sd.update({f'multiscale_discrs.{k}': v for k, v in self.multiscale_discrs.state_dict().items()})
+        vgg = self._modules.pop('vgg', None)                      # the reference's load_state_dict never sees the VGG either (@remove_vgg)
+        try:
+            out = super().load_state_dict(sd, strict=strict, **kw)
+        finally:
+            if vgg is not None:
+                self._modules['vgg'] = vgg
         self.refresh_weights()
         if self.discr is not None:
             self.discr.refresh_weights()

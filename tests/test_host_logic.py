@@ -610,7 +610,7 @@ def test_multiscale_discriminators_and_vgg_match_oracle():
     vgg = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, stride=2), torch.nn.ReLU(), torch.nn.Flatten())
     tok = VideoTokenizer(**GAN_KW, use_gan=True, vgg=vgg, perceptual_loss_weight=0.3, multiscale_discrs=ms, multiscale_adversarial_loss_weight=0.5, seed=0)
     keys = set(tok.state_dict())
-    assert {'multiscale_discrs.0.w', 'multiscale_discrs.1.w', 'vgg.0.weight', 'vgg.0.bias'} <= keys       # the reference's key names for these modules
+    assert {'multiscale_discrs.0.w', 'multiscale_discrs.1.w'} <= keys and not any(k.startswith('vgg.') for k in keys)     # reference: @remove_vgg
     tok.load_state_dict(sd)                                                                                # tokenizer-only checkpoint: the caller's modules keep their weights
     assert torch.equal(tok.multiscale_discrs[1].w, ms[1].w)
     tok._set_backend(CpuOps())
@@ -692,3 +692,33 @@ def test_facade_vs_reference_widened_feature_fixtures():
         tok.compute_dtype = torch.float32
         return tok
     _widened_feature_checks(make_tok, lambda t: t, tol_total=1e-5, tol_recon=2e-5, ids_frac=0.)
+
+
+def test_checkpoint_surface_parameters_and_copy_for_eval(tmp_path):
+    """reference :1459-1488: parameters() are the tokenizer's own, discr_parameters() the discriminator's, the VGG never enters a
+    state_dict, copy_for_eval() drops discriminator / VGG / multiscale discriminators and still encodes / decodes."""
+    from tests._util import ClipDiscr, tiny_vgg
+    cfg = make_cfg(**GAN_KW)
+    sd = init_state_dict(cfg, seed=5, randomize_se=True)
+    tok = VideoTokenizer(**GAN_KW, use_gan=True, vgg=tiny_vgg(3), perceptual_loss_weight=0.3, multiscale_discrs=(ClipDiscr(1),), seed=0)
+    tok.load_state_dict(sd)
+    keys = set(tok.state_dict())
+    assert not any(k.startswith('vgg.') for k in keys) and 'multiscale_discrs.0.w' in keys and any(k.startswith('discr.') for k in keys)
+    names = {n for n, _ in tok.named_parameters()}
+    own = tok.parameters()
+    assert isinstance(own, list) and len(own) == len([n for n in names if not n.startswith(('discr.', 'vgg.', 'multiscale_discrs.'))])
+    assert len(list(tok.discr_parameters())) == len([n for n in names if n.startswith('discr.')]) > 0
+    tok.save(str(tmp_path / 'a.pt'))
+    pkg = torch.load(str(tmp_path / 'a.pt'), weights_only=False)
+    assert not any(k.startswith('vgg.') for k in pkg['model_state_dict'])
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    v = torch.randn(1, 3, 5, 16, 16, generator=torch.Generator().manual_seed(6))
+    codes = tok(v, return_codes=True)
+    dup = tok.copy_for_eval()
+    assert dup.discr is None and dup.vgg is None and len(dup.multiscale_discrs) == 0 and not dup.training
+    assert not any(k.startswith(('discr.', 'vgg.', 'multiscale_discrs.')) for k in dup.state_dict())
+    dup._set_backend(CpuOps())
+    dup.compute_dtype = torch.float32
+    assert torch.equal(dup(v, return_codes=True), codes)
+    assert tok.discr is not None and tok.vgg is not None and tok._ops is not None        # the original is untouched
