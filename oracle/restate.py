@@ -241,12 +241,24 @@ def token_shift(x):
 
 
 # ----------------------------------------------------------------------------- quantizers
+def _project(t, p, which):
+    """quantizers.project_in / project_out: a Linear, or the identity when the latent width already equals the code width
+    (third-party `has_projections = dim != codebook_dims`: nn.Identity, no parameters in the state_dict)."""
+    w = p.get(f'quantizers.{which}.weight')
+    return t if w is None else t @ w.t() + p[f'quantizers.{which}.bias']
+
+
+def _code_dtype(p):
+    w = p.get('quantizers.project_out.weight')
+    return torch.float32 if w is None else w.dtype
+
+
 def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1., train=False):
     """third-party LFQ.forward eval path (reconstruction; see oracle/thirdparty.py)."""
     B, C = x.shape[:2]
     sp = x.shape[2:]
     tok = x.reshape(B, C, -1).transpose(1, 2)
-    z = tok @ p['quantizers.project_in.weight'].t() + p['quantizers.project_in.bias']
+    z = _project(tok, p, 'project_in')
     if clamp is not None:
         z = (z / clamp).tanh() * clamp
     z = z.reshape(B, -1, num_codebooks, codebook_dim).float()
@@ -257,7 +269,7 @@ def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1., train
     if train:
         q = z + (q - z)                                                        # straight-through value (forward: q up to fp32 rounding)
     q = q.to(x.dtype).reshape(B, -1, num_codebooks * codebook_dim)
-    out = q @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    out = _project(q, p, 'project_out')
     out = out.transpose(1, 2).reshape(B, C, *sp)
     ids = ids.reshape(B, *sp, num_codebooks)
     if num_codebooks == 1:
@@ -285,13 +297,13 @@ def lfq_train_losses(z, codebook_dim, num_codebooks, inv_temperature=100., diver
 
 
 def lfq_indices_to_codes(ids, p, codebook_dim, num_codebooks=1, scale=1.):
-    dtype = p['quantizers.project_out.weight'].dtype
+    dtype = _code_dtype(p)
     if num_codebooks == 1:
         ids = ids.unsqueeze(-1)
     mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
     bits = ((ids[..., None].int() & mask) != 0).to(dtype)
     codes = (bits * scale * 2 - scale).flatten(-2)
-    out = codes @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    out = _project(codes, p, 'project_out')
     return out.movedim(-1, 1)
 
 
@@ -309,20 +321,20 @@ def fsq_quantize(x, p, levels):
     B, C = x.shape[:2]
     sp = x.shape[2:]
     tok = x.reshape(B, C, -1).transpose(1, 2)
-    z = tok @ p['quantizers.project_in.weight'].t() + p['quantizers.project_in.bias']
+    z = _project(tok, p, 'project_in')
     L, basis, half_l, offset, shift, hw = _fsq_consts(levels, z.dtype)
     bounded = (z + shift).tanh() * half_l - offset
     codes = bounded.round() / hw
     ids = ((codes * hw + hw) * basis).sum(dim=-1).to(torch.int32)
-    out = codes.to(x.dtype) @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    out = _project(codes.to(x.dtype), p, 'project_out')
     return out.transpose(1, 2).reshape(B, C, *sp), ids.reshape(B, *sp), bounded.reshape(B, *sp, len(levels))
 
 
 def fsq_indices_to_codes(ids, p, levels):
     L, basis, half_l, offset, shift, hw = _fsq_consts(levels, torch.float32)
     lv = (ids.unsqueeze(-1) // basis) % L
-    codes = ((lv - hw) / hw).to(p['quantizers.project_out.weight'].dtype)
-    out = codes @ p['quantizers.project_out.weight'].t() + p['quantizers.project_out.bias']
+    codes = ((lv - hw) / hw).to(_code_dtype(p))
+    out = _project(codes, p, 'project_out')
     return out.movedim(-1, 1)
 
 

@@ -316,3 +316,27 @@ def test_forward_loss_separate_first_frame_and_headless_match_reference():
         ototal, d = orc.forward_loss(v, training=True, video_contains_first_frame=vcff)
         assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5), (frames, float(ototal), float(total))
         assert torch.allclose(d['recon_loss'], rl, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('kw', [
+    dict(image_size=16, init_dim=8, max_dim=8, codebook_size=256, layers=('residual', 'compress_space', 'residual')),              # 8 = log2(256)
+    dict(image_size=16, init_dim=8, max_dim=8, codebook_size=16, num_codebooks=2, layers=('residual', 'attend_space')),              # 8 = 2 x log2(16)
+    dict(image_size=16, init_dim=8, max_dim=8, use_fsq=True, fsq_levels=[4, 4, 3, 3, 3, 3, 2, 2], layers=('residual', 'compress_time')),  # 8 = len(levels)
+])
+def test_identity_projections_match_reference(kw):
+    """latent width == code width: the third-party quantizers use nn.Identity for project_in / project_out and the state_dict
+    has no `quantizers.project_*` entries; found by the randomized lowering sweep (tests/test_host_logic.py::test_random_specs)."""
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=31, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    rsd = {k: v for k, v in ref.state_dict().items() if not k.startswith('discr.')}
+    assert set(rsd) == set(sd) and not any('project_' in k for k in sd)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(32))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes)
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    assert ocodes.dtype == codes.dtype and torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
