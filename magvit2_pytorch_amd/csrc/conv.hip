@@ -466,7 +466,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.steps_per_split = L.steps_per_split; p.splitk = L.splitk;
     p.ws_cols = L.ws_cols; p.ws_rows = L.ws_rows;
     p.tiles_h = L.tiles_h; p.tiles_w = L.tiles_w; p.nchunk = L.nchunk; p.chunks_per_split = L.chunks_per_split;
-    p.ablate = 0;
+    p.aligned = 0;
     if (L.splitk > 1) {
         const size_t need = (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
         if (!workspace || workspace_bytes < need) return MV2_EWORKSPACE;

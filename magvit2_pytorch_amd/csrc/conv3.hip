@@ -124,7 +124,7 @@ __device__ unsigned long long* g_conv3_prof = nullptr;
 #define C3_SUB(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); qf_[k] += n_ - pt_; pf_[4] += n_ - pt_; pt_ = n_; }
 #define C3_PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
 #define C3_PROF_COUNT(k, v) pf_[k] += (v);
-#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; for (int i_ = 0; i_ < 8; ++i_) { g_conv3_prof[(size_t)blockIdx.x * 16 + i_] = pf_[i_]; g_conv3_prof[(size_t)blockIdx.x * 16 + 8 + i_] = qf_[i_]; } }
+#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; qf_[7] = pt0_; for (int i_ = 0; i_ < 8; ++i_) { g_conv3_prof[(size_t)blockIdx.x * 16 + i_] = pf_[i_]; g_conv3_prof[(size_t)blockIdx.x * 16 + 8 + i_] = qf_[i_]; } }
 #else
 #define C3_PROF_DECL
 #define C3_PROF(k)
@@ -155,7 +155,20 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         const uint32_t q = NW >> 3, r = NW & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const uint32_t x0 = start_of(bid, NW, G), x1 = start_of(bid + 1, NW, G);
+    // Worker ranges.  Stream-K proper cuts tiles at arbitrary units (equal work, but every cut costs a slab round trip, a ticket
+    // and a second cross-wave reduce).  Where a worker owns >= 4 tiles (p.aligned, decided by the host: C = 64 at batch 1, every
+    // level up to C = 256 at batch 4) the range ends are snapped to the nearest tile start instead: no tile is cut, so no slab
+    // traffic, no ticket, no partial reduce, at the price of up to half a tile of imbalance per range end.  Measured (k3_bench,
+    // profiles/r02_k3_align.log): batch 4 C = 64 / 128 / 256 350 / 291 / 276 -> 319 / 273 / 247 us; batch 1 C = 64 94 -> 83 us.
+    auto range_start = [&](uint32_t w) -> uint32_t {
+        const uint32_t x = start_of(w, NW, G);
+        if (!p.aligned || x >= G) return x;
+        uint32_t gv;
+        const TileInfo t = decode_unit(p, x, gv);
+        const uint32_t vs = t.ng + p.delta;
+        return 2 * gv < vs ? t.G0 : t.G0 + vs;
+    };
+    const uint32_t x0 = __builtin_amdgcn_readfirstlane(range_start(bid)), x1 = __builtin_amdgcn_readfirstlane(range_start(bid + 1));
 
     const uint32_t row_bytes = (uint32_t)d.Ci * E::kBytes;
     const uint32_t frame_bytes = (uint32_t)((int64_t)H * W_ * d.Ci * E::kBytes);
@@ -576,6 +589,7 @@ struct Plan3 {
     uint64_t gtot, units;      // real 9-tap groups; work-list units = groups + delta per tile
     uint32_t delta;
     int workers;
+    int aligned;               // worker ranges snapped to tile starts (no cut tiles)
     size_t slab_bytes;
 };
 
@@ -621,6 +635,11 @@ inline Plan3 plan3(const mv2_conv_desc& d) {
     if (P.gtot < (uint64_t)P.workers * 4) P.workers = (int)std::min<uint64_t>((uint64_t)cus, P.gtot);
 #ifdef MV2_EXPERIMENTS
     if (const char* e = getenv("MV2_C3_WORKERS")) { const int v = atoi(e); if (v > 0) P.workers = (int)std::min<uint64_t>((uint64_t)v, P.gtot); }
+#endif
+    // tile-aligned ranges where a worker owns at least four tiles (see the kernel): half a tile of imbalance is then <= 12 %
+    P.aligned = P.n_tiles >= (int64_t)4 * P.workers ? 1 : 0;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3_ALIGN")) P.aligned = atoi(e) != 0;
 #endif
     // two slab slots per worker (a worker's range cuts at most its first and its last tile)
     P.slab_bytes = P.workers > 1 ? (size_t)2 * P.workers * SLAB_BYTES : 0;
@@ -697,6 +716,7 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
     p.M = P.M; p.n_co_tiles = P.n_co_tiles; p.n_pos_tiles = (int)(P.n_tiles / P.n_co_tiles);
     p.splitk = 1; p.tiles_h = P.tiles_h; p.tiles_w = P.tiles_w; p.nchunk = P.nchunk; p.chunks_per_split = P.nchunk;
     p.counters = counters; p.gtot = (uint32_t)P.units; p.delta = P.delta; p.ws_bytes = (uint32_t)P.slab_bytes;
+    p.aligned = P.aligned;
     hipStream_t st = (hipStream_t)stream;
     if (wp2) return launch3<BF16, true>(p, P.workers, st);
     return d->dtype == MV2_BF16 ? launch3<BF16, false>(p, P.workers, st) : launch3<F32, false>(p, P.workers, st);

@@ -27,7 +27,7 @@ struct ConvParams {
     int64_t ws_rows;
     // tile grid of the 3x3 kernel (conv3.hip)
     int32_t tiles_h, tiles_w, nchunk, chunks_per_split;
-    int32_t ablate;   // unused (kept zero)
+    int32_t aligned;  // conv3.hip: worker ranges snapped to tile starts (0 for every other kernel)
     // fused second stage (mv2_conv3 with wp2): 1x1x1 conv over the block's own output channels
     const void* wp2;
     const float* bias2;

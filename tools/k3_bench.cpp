@@ -258,6 +258,21 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
             for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) { ++nw; for (int k = 0; k < 8; ++k) { sum[k] += (double)hp[w * 16 + k]; sub[k] += (double)hp[w * 16 + 8 + k]; } if (hp[w * 16 + 7] > mx7) mx7 = (double)hp[w * 16 + 7]; }
             if (nw) printf("   prof %s (avg clocks / workgroup, %d wgs): prologue %.0f  taps %.0f (%.0f per tap)  reduce %.0f  ticket %.0f  epilogue %.0f | segments %.2f groups %.1f | kernel avg %.0f max %.0f\n",
                            fz ? "fused" : "plain", nw, sum[0] / nw, sum[1] / nw, sum[1] / (sum[6] * 9), sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw, mx7);
+            if (nw && getenv("K3_DIST")) {      // start skew, end-time distribution and the slowest workgroups (qf[7] = absolute start clock)
+                unsigned long long s0 = ~0ull, e1 = 0; std::vector<std::pair<double, int>> byend;
+                for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) { s0 = std::min(s0, hp[w * 16 + 15]); e1 = std::max(e1, hp[w * 16 + 15] + hp[w * 16 + 7]); }
+                double sk_sum = 0, sk_max = 0;
+                for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) { const double sk = (double)(hp[w * 16 + 15] - s0); sk_sum += sk; sk_max = std::max(sk_max, sk); byend.push_back({(double)(hp[w * 16 + 15] + hp[w * 16 + 7] - s0), w}); }
+                std::sort(byend.begin(), byend.end());
+                printf("        span first start -> last end %.0f | start skew avg %.0f max %.0f | end times p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n", (double)(e1 - s0), sk_sum / nw, sk_max,
+                       byend[nw / 10].first, byend[nw / 2].first, byend[nw * 9 / 10].first, byend[nw * 99 / 100].first, byend[nw - 1].first);
+                for (int k = 0; k < 6; ++k) { const int w = byend[nw - 1 - k].second;
+                    printf("        late wg %4d (xcd %d): start +%.0f dur %llu | segs %llu groups %llu taps %llu reduce %llu ticket %llu epi %llu\n", w, w & 7, (double)(hp[w * 16 + 15] - s0),
+                           hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]); }
+                for (int k = 0; k < 3; ++k) { const int w = byend[k].second;
+                    printf("        early wg %4d (xcd %d): start +%.0f dur %llu | segs %llu groups %llu taps %llu reduce %llu ticket %llu epi %llu\n", w, w & 7, (double)(hp[w * 16 + 15] - s0),
+                           hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]); }
+            }
             if (nw) printf("        epilogue parts per SEGMENT: put_tile %.0f  gemm2 %.0f  put_tile2 %.0f  row stores %.0f  SE %.0f  (to barrier %.0f, barrier %.0f)\n",
                            sub[0] / sum[5], sub[1] / sum[5], sub[2] / sum[5], sub[3] / sum[5], sub[4] / sum[5], sub[5] / sum[5], sub[6] / sum[5]);
         }
@@ -279,6 +294,37 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
             printf("   delta sweep (min / median us):");
             for (int k = 0; k < 6; ++k) { std::sort(ts[k].begin(), ts[k].end()); printf("  d%d: %.1f / %.1f", dls[k], ts[k][0], ts[k][3]); }
             printf("\n");
+        }
+        if (getenv("K3_ALIGN")) {      // tile-aligned worker ranges (experiments build): correctness against the default split + timing, per delta
+            std::vector<uint8_t> o_al(b.out_bytes);
+            setenv("MV2_C3_ALIGN", "1", 1);
+            CK(hipMemset(b.out, 0xff, b.out_bytes));
+            run_new(c, b, false, false, st); CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(o_al.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost));
+            Diff da = compare(o_al, to_float(o_new, n, es), es, atol * 0.5, rtol * 0.5);
+            printf("   aligned ranges vs default split: max|d| %.3e bad %zu / %zu  %s\n", da.max_abs, da.nbad, n, da.nbad ? "FAIL" : "ok");
+            ok &= da.nbad == 0;
+            printf("   aligned sweep (min / median us over 5 rounds) default: ");
+            std::vector<float> td;
+            unsetenv("MV2_C3_ALIGN");
+            for (int r = 0; r < 5; ++r) td.push_back(time_us([&] { run_new(c, b, false, false, st); }, 5, st));
+            std::sort(td.begin(), td.end()); printf("%.1f / %.1f |", td[0], td[2]);
+            for (int dl : {0, 1, 3}) for (int wk : {512, 256}) {
+                char buf[16]; snprintf(buf, sizeof buf, "%d", dl); setenv("MV2_C3_DELTA", buf, 1);
+                snprintf(buf, sizeof buf, "%d", wk); setenv("MV2_C3_WORKERS", buf, 1);
+                setenv("MV2_C3_ALIGN", "1", 1);
+                std::vector<float> ta;
+                for (int r = 0; r < 5; ++r) ta.push_back(time_us([&] { run_new(c, b, false, false, st); }, 5, st));
+                std::sort(ta.begin(), ta.end()); printf("  aligned d%d w%d: %.1f / %.1f", dl, wk, ta[0], ta[2]);
+            }
+            unsetenv("MV2_C3_ALIGN"); unsetenv("MV2_C3_DELTA"); unsetenv("MV2_C3_WORKERS"); printf("\n");
+            if (do_fused && fusable) {
+                const float tf0 = time_us([&] { run_new(c, b, true, true, st); }, reps, st);
+                setenv("MV2_C3_ALIGN", "1", 1);
+                const float tf1 = time_us([&] { run_new(c, b, true, true, st); }, reps, st);
+                unsetenv("MV2_C3_ALIGN");
+                printf("   fused: default %.1f us, aligned %.1f us\n", tf0, tf1);
+            }
         }
         if (getenv("K3_SWEEP")) {
             printf("   workers sweep   :");
@@ -368,8 +414,9 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    const bool quick = argc > 2 && (!strcmp(argv[2], "quick") || !strcmp(argv[2], "levels"));
-    const bool levels_only = argc > 2 && !strcmp(argv[2], "levels");
+    const bool levels4 = argc > 2 && !strcmp(argv[2], "levels4");      // levels at batch 1, then the three large levels at batch 4 (no CPU-reference cases)
+    const bool quick = argc > 2 && (!strcmp(argv[2], "quick") || !strcmp(argv[2], "levels") || levels4);
+    const bool levels_only = argc > 2 && (!strcmp(argv[2], "levels") || levels4);
     hipStream_t st; CK(hipStreamCreate(&st));
     bool ok = true;
     // small shapes against the CPU reference: ragged tiles, kt = 1/2/3, batch > 1, both dtypes, every channel width
@@ -384,6 +431,10 @@ int main(int argc, char** argv) {
     // the level shapes of BASELINE configs[1] (B = 1) and configs[2] (B = 4): A/B against the round-1 kernel + timing
     const Shape levels[] = {{1, 20, 128, 128, 64, 3}, {1, 20, 64, 64, 128, 3}, {1, 20, 32, 32, 256, 3}, {1, 20, 16, 16, 512, 3}, {1, 10, 16, 16, 512, 3}, {1, 5, 16, 16, 512, 3}};
     for (const Shape& s : levels) ok &= test_shape(s, 2, false, true, true, quick ? 5 : 20, st);
+    if (levels4) {
+        const Shape b4[] = {{4, 20, 128, 128, 64, 3}, {4, 20, 64, 64, 128, 3}, {4, 20, 32, 32, 256, 3}};
+        for (const Shape& s : b4) ok &= test_shape(s, 2, false, false, false, 5, st);
+    }
     if (!quick) {
         const Shape b4[] = {{4, 20, 128, 128, 64, 3}, {4, 20, 64, 64, 128, 3}, {4, 20, 32, 32, 256, 3}, {4, 20, 16, 16, 512, 3}, {4, 5, 16, 16, 512, 3}};
         for (const Shape& s : b4) ok &= test_shape(s, 2, false, true, false, 10, st);
