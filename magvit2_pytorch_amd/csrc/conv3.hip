@@ -97,8 +97,36 @@ constexpr int ROWP = 144;                                             // LDS pit
 constexpr int HALO_BYTES = ((HR * ROWP + 255) / 256) * 256;
 constexpr int RED_BYTES = 4 * 4 * 4096;                               // cross-wave reduce round: [src wave][4 tiles] x 4 KB
 constexpr int SLAB_BYTES = BCO * BPOS * 4;
-constexpr int WD = 3;                                                 // weight register sets (prefetch distance in taps)
-constexpr int HWT = 5;                                                // tap at which the prefetched halo goes into the idle image
+// Weight fragments (1 KB per wave, 16 B per lane) stream global -> VGPR through a ring of RING slots: a group consumes 18
+// fragments (9 taps x 2 channel tiles), fragment f lives in slot f % RING and its slot is refilled with fragment f + RING right
+// behind its last MFMA, so RING must divide 18 for the slot of a fragment to be a compile-time constant.  RING = 6 is a
+// prefetch distance of 3 taps, RING = 9 of 4.5 taps (12 more registers; paid for by HSPLIT).
+#ifndef MV2_C3_RING
+#define MV2_C3_RING 6
+#endif
+// HSPLIT: the next group's halo travels in two halves (rows 0-2 issued at tap 0 and written at tap 4, rows 3-5 issued at tap 4
+// and written at tap 8) instead of six loads parked in registers from tap 0 to tap 5: 12 registers less inside the tap loop.
+#ifndef MV2_C3_HSPLIT
+#define MV2_C3_HSPLIT 0
+#endif
+// PRIO (experiments): the two workgroups of a CU start together and the older one wins every issue arbitration, so it runs at its
+// solo rate (~400 clocks per tap), finishes early, and the younger one does most of its taps alone afterwards (k3_bench residency
+// report: 80k against 122k clocks for equal work).  PRIO = 1 alternates s_setprio between the pair per 9-tap group, PRIO = 2 per tap
+// (both measured: the pair ends closer, 96k / 119k, the launch is not faster — a group counter is not a shared clock, whoever is
+// ahead by an odd number of groups has the partner's priority and wins on age).  PRIO = 3 (not yet measured) slices by the CU's
+// own clock: bit 13 of s_memtime picks which workgroup of the pair is favoured, whatever their progress.
+#ifndef MV2_C3_PRIO
+#define MV2_C3_PRIO 0
+#endif
+// ABL (experiments, TIMING ONLY — results are wrong): 1 = the a = 1 weight fragments are never reloaded (-37 % of the bytes a wave
+// pulls through L1), 2 = no weight fragment is reloaded (-75 %), 3 = the position fragments are not re-read from LDS, 4 = 2 + 3.
+// Separates "bound by vector-memory throughput" from "bound by issue / dependencies" in the tap loop.
+#ifndef MV2_C3_ABL
+#define MV2_C3_ABL 0
+#endif
+constexpr int RING = MV2_C3_RING;
+static_assert(18 % RING == 0 && RING >= 2, "ring slots must divide the 18 fragments of a group");
+constexpr int HWT = 5;                                                // tap at which the prefetched halo goes into the idle image (HSPLIT = 0)
 
 template <typename E, bool FUSED>
 struct C3Lds {
@@ -124,7 +152,7 @@ __device__ unsigned long long* g_conv3_prof = nullptr;
 #define C3_SUB(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); qf_[k] += n_ - pt_; pf_[4] += n_ - pt_; pt_ = n_; }
 #define C3_PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[k] += n_ - pt_; pt_ = n_; }
 #define C3_PROF_COUNT(k, v) pf_[k] += (v);
-#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; qf_[7] = pt0_; for (int i_ = 0; i_ < 8; ++i_) { g_conv3_prof[(size_t)blockIdx.x * 16 + i_] = pf_[i_]; g_conv3_prof[(size_t)blockIdx.x * 16 + 8 + i_] = qf_[i_]; } }
+#define C3_PROF_END if (g_conv3_prof && threadIdx.x == 0) { pf_[7] = __builtin_amdgcn_s_memtime() - pt0_; qf_[7] = pt0_; pf_[5] |= ((unsigned long long)((__builtin_amdgcn_s_getreg(63508) & 0xf) << 8 | ((__builtin_amdgcn_s_getreg(63492) >> 8) & 0xff))) << 32; for (int i_ = 0; i_ < 8; ++i_) { g_conv3_prof[(size_t)blockIdx.x * 16 + i_] = pf_[i_]; g_conv3_prof[(size_t)blockIdx.x * 16 + 8 + i_] = qf_[i_]; } }
 #else
 #define C3_PROF_DECL
 #define C3_PROF(k)
@@ -207,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         uint32_t cur_wb, nxt_wb;
     };
     i32x4 hreg[NH];
-    i32x4 wset[WD][WCO], pset[3][WPOS];
+    i32x4 wring[RING], pset[3][WPOS];
     i32x4 bias_v;                                       // lanes 0..15 of the block: the segment's 64 bias values (part of the prefetch stream)
 
     auto advance = [&](const Seg& S, int& chunk, int& it) {
@@ -248,13 +276,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         return S;
     };
     // every load is unconditional in instruction count (spatial padding -> out-of-range offset -> zeros, no traffic)
-    auto issue_halo = [&](const Seg& S, int chunk, int it) {
+    auto issue_halo = [&](const Seg& S, int chunk, int it, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int t_in = S.ti.t + it - d.pt;                        // >= 0 by construction of the group list
         const uint32_t base = (uint32_t)(((int64_t)S.ti.b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + S.hw_base;
         int r0_ = r0;
         asm volatile("" : "+v"(r0_));          // recompute the six row offsets per group: cheaper than six live registers (VGPR budget)
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
+        for (int i = LO; i < HI; ++i) {
             const int hr = r0_ + RPP * i;
             const int hy = hr / HWD, hx = hr - hy * HWD;
             const bool ok = (S.hmask >> i) & 1u;
@@ -262,21 +291,20 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
     };
-    auto write_halo = [&](char* img) {
+    auto write_halo = [&](char* img, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
-        for (int i = 0; i < NH; ++i)
+        for (int i = LO; i < HI; ++i)
             if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hreg[i];
     };
     auto issue_w1 = [&](const Seg& S, uint32_t so, int a, i32x4& dst) {
         dst = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)S.w_off0, (int)(so + (uint32_t)(a * 4096)), 0);
     };
-    auto issue_first = [&](const Seg& S) {     // halo of the segment's first group + its first WD weight taps + its bias values
-        issue_halo(S, S.cur_chunk, S.cur_it);
+    auto issue_first = [&](const Seg& S) {     // halo of the segment's first group + the first RING weight fragments + its bias values
+        issue_halo(S, S.cur_chunk, S.cur_it, IC<0>{}, IC<NH>{});
         bias_v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(tid < 16 ? (uint32_t)(S.ti.co_tile * BCO + tid * 4) * 4u : 0xfffffff0u), 0, 0);
 #pragma unroll
-        for (int q = 0; q < WD; ++q)
-#pragma unroll
-            for (int a = 0; a < WCO; ++a) issue_w1(S, S.cur_wb + (uint32_t)q * tapstride, a, wset[q][a]);
+        for (int f = 0; f < RING; ++f) issue_w1(S, S.cur_wb + (uint32_t)(f / WCO) * tapstride, f % WCO, wring[f]);
     };
     auto read_p = [&](uint32_t img, int tp, auto set_c) {     // img: LDS byte offset of the halo image
         constexpr int SET = decltype(set_c)::value;
@@ -285,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         for (int bb = 0; bb < WPOS; ++bb) pset[SET][bb] = *(const i32x4*)(smem + (pbase[bb] + img) + toff);
     };
 
+    const int prio_par = MV2_C3_PRIO ? (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0) : 0;     // the CU's pair is (w, w + NW / 2)
     C3_PROF_DECL
     // first segment with real groups (a range may begin or end inside a tile's virtual units)
     auto next_seg = [&](uint32_t x, Seg& O) {
@@ -307,34 +336,49 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             for (int bb = 0; bb < WPOS; ++bb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
-        write_halo(smem);
+        write_halo(smem, IC<0>{}, IC<NH>{});
         __syncthreads();
         read_p(0u, 0, IC<0>{});
         C3_PROF(0)
 
-        // one tap.  Weights of tap TP live in set TP % WD, requested WD taps ago; pset[TP % 3] holds the position fragments,
-        // read one tap ago.  The reload of a weight fragment is issued right behind the last MFMA that reads it, so loads,
-        // LDS reads and MFMAs interleave instead of forming phases.
+        // one tap.  Fragment f = 2 TP + a of the group lives in ring slot f % RING, requested RING fragments ago; pset[TP % 3] holds
+        // the position fragments, read one tap ago.  The reload of a slot is issued right behind the last MFMA that reads it, so
+        // loads, LDS reads and MFMAs interleave instead of forming phases.
         auto tap = [&](uint32_t img, uint32_t other, auto tp_c) {
             constexpr int TP = decltype(tp_c)::value;
-            constexpr int SET = TP % 3, NSET = (TP + 1) % 3, WS = TP % WD;
-            if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it);
+            constexpr int SET = TP % 3, NSET = (TP + 1) % 3;
+            if constexpr (MV2_C3_PRIO == 2) { if ((TP & 1) ^ prio_par) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+            if constexpr (MV2_C3_HSPLIT) {
+                if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH / 2>{});
+                if constexpr (TP == 4) { write_halo(smem + other, IC<0>{}, IC<NH / 2>{}); issue_halo(S, S.nxt_chunk, S.nxt_it, IC<NH / 2>{}, IC<NH>{}); }
+                if constexpr (TP == 8) write_halo(smem + other, IC<NH / 2>{}, IC<NH>{});
+            } else {
+                if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH>{});
+            }
             if constexpr (TP == 8) __syncthreads();       // the next group's image is complete; this one has no reader left
-            if constexpr (TP < 8) read_p(img, TP + 1, IC<NSET>{});
+            if constexpr (MV2_C3_ABL == 3 || MV2_C3_ABL == 4) {
+#pragma unroll
+                for (int bb = 0; bb < WPOS; ++bb) { pset[NSET][bb] = pset[SET][bb]; asm volatile("" : "+v"(pset[NSET][bb])); }
+            } else if constexpr (TP < 8) read_p(img, TP + 1, IC<NSET>{});
             else read_p(other, 0, IC<NSET>{});
             __builtin_amdgcn_sched_barrier(0);            // keep the fragment reads of the NEXT tap at the top (the scheduler sinks them to their use)
-            const uint32_t so = (TP + WD < 9 ? S.cur_wb + (uint32_t)(TP + WD) * tapstride : S.nxt_wb + (uint32_t)(TP + WD - 9) * tapstride);
+            auto frag = [&](auto a_c) {
+                constexpr int A = decltype(a_c)::value, F = TP * WCO + A, SLOT = F % RING, G = F + RING;
 #pragma unroll
-            for (int a = 0; a < WCO; ++a) {
-#pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(wset[WS][a], pset[SET][bb], acc[a][bb]);
-                issue_w1(S, so, a, wset[WS][a]);
-            }
-            if constexpr (TP == HWT) write_halo(smem + other);   // image of group gi-1: its last reader passed the previous barrier
+                for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(wring[SLOT], pset[SET][bb], acc[A][bb]);
+                const uint32_t so = G < 9 * WCO ? S.cur_wb + (uint32_t)(G / WCO) * tapstride : S.nxt_wb + (uint32_t)((G - 9 * WCO) / WCO) * tapstride;
+                if constexpr (!(MV2_C3_ABL == 2 || MV2_C3_ABL == 4 || (MV2_C3_ABL == 1 && A == 1))) issue_w1(S, so, G % WCO, wring[SLOT]);
+                else asm volatile("" : "+v"(wring[SLOT]));       // keep the slot live and opaque
+            };
+            static_assert(WCO == 2, "two channel tiles per wave");
+            frag(IC<0>{}); frag(IC<1>{});
+            if constexpr (!MV2_C3_HSPLIT && TP == HWT) write_halo(smem + other, IC<0>{}, IC<NH>{});   // image of group gi-1: its last reader passed the previous barrier
             __builtin_amdgcn_sched_barrier(0);
         };
         for (int gi = S.gb; gi < S.ge; ++gi) {
             const int par = (gi - S.gb) & 1;
+            if constexpr (MV2_C3_PRIO == 1) { if ((gi + prio_par) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+            if constexpr (MV2_C3_PRIO == 3) { if ((int)((__builtin_amdgcn_s_memtime() >> 13) & 1) ^ prio_par) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             const uint32_t img = (uint32_t)(par * HALO_BYTES), other = (uint32_t)((par ^ 1) * HALO_BYTES);
             tap(img, other, IC<0>{}); tap(img, other, IC<1>{}); tap(img, other, IC<2>{});
             tap(img, other, IC<3>{}); tap(img, other, IC<4>{}); tap(img, other, IC<5>{});
@@ -342,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             S.cur_wb = S.nxt_wb;
             if (gi + 2 < S.ge) { advance(S, S.nxt_chunk, S.nxt_it); S.nxt_wb = wbase_of(S.nxt_chunk, S.nxt_it); }
         }
+        if constexpr (MV2_C3_PRIO != 0) __builtin_amdgcn_s_setprio(3);     // fixed phases: short, and they gate the next tile
         if (tid < 16) *(i32x4*)(smem + L::kBias + tid * 16) = bias_v;     // epilogue reads bias from LDS: no global load behind the next prefetch
         __syncthreads();                                    // halo images are dead: LDS becomes the reduce region
         C3_PROF(1)

@@ -255,6 +255,8 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
             p_setprof(nullptr);
             std::vector<unsigned long long> hp(NWK * 16); CK(hipMemcpy(hp.data(), dprof, NWK * 128, hipMemcpyDeviceToHost));
             double sum[8] = {0}, sub[8] = {0}; int nw = 0; double mx7 = 0;
+            std::vector<unsigned> cuid(NWK, 0);
+            for (int w = 0; w < NWK; ++w) { cuid[w] = (unsigned)(hp[w * 16 + 5] >> 32); hp[w * 16 + 5] &= 0xffffffffull; }
             for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) { ++nw; for (int k = 0; k < 8; ++k) { sum[k] += (double)hp[w * 16 + k]; sub[k] += (double)hp[w * 16 + 8 + k]; } if (hp[w * 16 + 7] > mx7) mx7 = (double)hp[w * 16 + 7]; }
             if (nw) printf("   prof %s (avg clocks / workgroup, %d wgs): prologue %.0f  taps %.0f (%.0f per tap)  reduce %.0f  ticket %.0f  epilogue %.0f | segments %.2f groups %.1f | kernel avg %.0f max %.0f\n",
                            fz ? "fused" : "plain", nw, sum[0] / nw, sum[1] / nw, sum[1] / (sum[6] * 9), sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw, mx7);
@@ -269,6 +271,29 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
                 for (int k = 0; k < 6; ++k) { const int w = byend[nw - 1 - k].second;
                     printf("        late wg %4d (xcd %d): start +%.0f dur %llu | segs %llu groups %llu taps %llu reduce %llu ticket %llu epi %llu\n", w, w & 7, (double)(hp[w * 16 + 15] - s0),
                            hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]); }
+                {   // residency: workgroups per CU (key = xcc << 8 | se/sh/cu bits of HW_ID), and how a CU's workgroups compare
+                    std::vector<std::pair<unsigned, int>> bycu;
+                    for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) bycu.push_back({cuid[w], w});
+                    std::sort(bycu.begin(), bycu.end());
+                    int hist[8] = {0}, ncu = 0; size_t i = 0;
+                    double rate1 = 0, rate2 = 0; int n1 = 0, n2 = 0;
+                    while (i < bycu.size()) { size_t j = i; while (j < bycu.size() && bycu[j].first == bycu[i].first) ++j; const int cnt = (int)(j - i); hist[std::min(cnt, 7)]++; ++ncu;
+                        for (size_t k = i; k < j; ++k) { const int w = bycu[k].second; const double r = (double)hp[w * 16 + 1] / ((double)hp[w * 16 + 6] * 9); if (cnt == 1) { rate1 += r; ++n1; } else { rate2 += r; ++n2; } }
+                        i = j; }
+                    printf("        residency: %d distinct CUs; CUs hosting 1/2/3/4+ workgroups: %d / %d / %d / %d | clocks per tap on single-wg CUs %.0f (%d wgs), on shared CUs %.0f (%d wgs)\n", ncu, hist[1], hist[2], hist[3],
+                           hist[4] + hist[5] + hist[6] + hist[7], n1 ? rate1 / n1 : 0., n1, n2 ? rate2 / n2 : 0., n2);
+                    std::vector<std::pair<double, int>> bydur; for (int w = 0; w < NWK; ++w) if (hp[w * 16 + 7]) bydur.push_back({(double)hp[w * 16 + 7], w});
+                    std::sort(bydur.begin(), bydur.end());
+                    for (int k = 0; k < 5; ++k) { const int w = bydur[nw - 1 - k].second;
+                        printf("        slow wg %4d cu %04x: dur %llu | segs %llu groups %llu taps %llu (%.0f/tap) reduce %llu ticket %llu epi %llu | same CU:", w, cuid[w], hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1],
+                               (double)hp[w * 16 + 1] / (hp[w * 16 + 6] * 9.0), hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]);
+                        for (int v = 0; v < NWK; ++v) if (v != w && hp[v * 16 + 7] && cuid[v] == cuid[w]) printf(" wg %d dur %llu groups %llu start %+lld", v, hp[v * 16 + 7], hp[v * 16 + 6], (long long)(hp[v * 16 + 15] - hp[w * 16 + 15]));
+                        printf("\n"); }
+                    for (int k = 0; k < 5; ++k) { const int w = bydur[k].second;
+                        printf("        fast wg %4d cu %04x: dur %llu | segs %llu groups %llu taps %llu (%.0f/tap) | same CU:", w, cuid[w], hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], (double)hp[w * 16 + 1] / (hp[w * 16 + 6] * 9.0));
+                        for (int v = 0; v < NWK; ++v) if (v != w && hp[v * 16 + 7] && cuid[v] == cuid[w]) printf(" wg %d dur %llu groups %llu start %+lld", v, hp[v * 16 + 7], hp[v * 16 + 6], (long long)(hp[v * 16 + 15] - hp[w * 16 + 15]));
+                        printf("\n"); }
+                }
                 for (int k = 0; k < 3; ++k) { const int w = byend[k].second;
                     printf("        early wg %4d (xcd %d): start +%.0f dur %llu | segs %llu groups %llu taps %llu reduce %llu ticket %llu epi %llu\n", w, w & 7, (double)(hp[w * 16 + 15] - s0),
                            hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]); }
