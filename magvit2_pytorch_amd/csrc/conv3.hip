@@ -124,6 +124,29 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 #ifndef MV2_C3_ABL
 #define MV2_C3_ABL 0
 #endif
+// AGPR (experiments): the tap loop's MFMAs are emitted through inline asm with the accumulator constrained to the accumulator
+// register file ("+a").  Under the 256-register budget the compiler selects the VGPR form of the MFMA (C / D in arch VGPRs,
+// .agpr_count 0); the measured ~49-cycle solo cadence of those MFMAs against the pipe's 32 may be the price of that form
+// (tools/mfma_cadence.cpp measures it in isolation).  bf16 only; the accumulators are copied to VGPRs for the reduce.
+#ifndef MV2_C3_AGPR
+#define MV2_C3_AGPR 0
+#endif
+// PSETS (experiments): register sets of position fragments.  3 (product) lets set (TP + 2) % 3 rest for a tap; 2 is a plain double
+// buffer (16 registers less): 9 taps per group is odd, so the fragments of the next group's first tap are moved from set 1 to
+// set 0 at the end of tap 8 (16 v_mov per group).
+#ifndef MV2_C3_PSETS
+#define MV2_C3_PSETS 3
+#endif
+constexpr int PSETS = MV2_C3_PSETS;
+static_assert(PSETS == 2 || PSETS == 3, "position fragment sets");
+template <typename E> struct TapMma { static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) { Mma<E>::run(a, b, acc); } };
+#if MV2_C3_AGPR
+template <> struct TapMma<BF16> {
+    static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+};
+#endif
 constexpr int RING = MV2_C3_RING;
 static_assert(18 % RING == 0 && RING >= 2, "ring slots must divide the 18 fragments of a group");
 constexpr int HWT = 5;                                                // tap at which the prefetched halo goes into the idle image (HSPLIT = 0)
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         uint32_t cur_wb, nxt_wb;
     };
     i32x4 hreg[NH];
-    i32x4 wring[RING], pset[3][WPOS];
+    i32x4 wring[RING], pset[PSETS][WPOS];
     i32x4 bias_v;                                       // lanes 0..15 of the block: the segment's 64 bias values (part of the prefetch stream)
 
     auto advance = [&](const Seg& S, int& chunk, int& it) {
@@ -341,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         read_p(0u, 0, IC<0>{});
         C3_PROF(0)
 
-        // one tap.  Fragment f = 2 TP + a of the group lives in ring slot f % RING, requested RING fragments ago; pset[TP % 3] holds
+        // one tap.  Fragment f = 2 TP + a of the group lives in ring slot f % RING, requested RING fragments ago; pset[TP % PSETS] holds
         // the position fragments, read one tap ago.  The reload of a slot is issued right behind the last MFMA that reads it, so
         // loads, LDS reads and MFMAs interleave instead of forming phases.
         auto tap = [&](uint32_t img, uint32_t other, auto tp_c) {
             constexpr int TP = decltype(tp_c)::value;
-            constexpr int SET = TP % 3, NSET = (TP + 1) % 3;
+            constexpr int SET = TP % PSETS, NSET = (TP + 1) % PSETS;
             if constexpr (MV2_C3_PRIO == 2) { if ((TP & 1) ^ prio_par) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             if constexpr (MV2_C3_HSPLIT) {
                 if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH / 2>{});
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             auto frag = [&](auto a_c) {
                 constexpr int A = decltype(a_c)::value, F = TP * WCO + A, SLOT = F % RING, G = F + RING;
 #pragma unroll
-                for (int bb = 0; bb < WPOS; ++bb) Mma<E>::run(wring[SLOT], pset[SET][bb], acc[A][bb]);
+                for (int bb = 0; bb < WPOS; ++bb) TapMma<E>::run(wring[SLOT], pset[SET][bb], acc[A][bb]);
                 const uint32_t so = G < 9 * WCO ? S.cur_wb + (uint32_t)(G / WCO) * tapstride : S.nxt_wb + (uint32_t)((G - 9 * WCO) / WCO) * tapstride;
                 if constexpr (!(MV2_C3_ABL == 2 || MV2_C3_ABL == 4 || (MV2_C3_ABL == 1 && A == 1))) issue_w1(S, so, G % WCO, wring[SLOT]);
                 else asm volatile("" : "+v"(wring[SLOT]));       // keep the slot live and opaque
@@ -373,6 +396,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             static_assert(WCO == 2, "two channel tiles per wave");
             frag(IC<0>{}); frag(IC<1>{});
             if constexpr (!MV2_C3_HSPLIT && TP == HWT) write_halo(smem + other, IC<0>{}, IC<NH>{});   // image of group gi-1: its last reader passed the previous barrier
+            if constexpr (PSETS == 2 && TP == 8) {      // the next group's tap 0 reads set 0
+#pragma unroll
+                for (int bb = 0; bb < WPOS; ++bb) pset[0][bb] = pset[1][bb];
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         for (int gi = S.gb; gi < S.ge; ++gi) {

@@ -18,7 +18,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // One wave issues ITERS x NACC MFMAs over NACC independent accumulators; FILL independent v_fma between two MFMAs.
-template <int NACC, int FILL, int MINB>
+// AGPR = 1 forces the accumulators into the accumulator file through an inline-asm "+a" constraint (under a 256-register budget the
+// compiler otherwise picks the VGPR form of the MFMA: C / D in arch VGPRs, .agpr_count 0)
+template <int NACC, int FILL, int MINB, int AGPR = 0>
 __global__ __launch_bounds__(256, MINB) void cadence_kernel(unsigned long long* out, float* sink, int iters) {
     f32x16 acc[NACC];
 #pragma unroll
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(256, MINB) void cadence_kernel(unsigned long long* 
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
-            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc[a], 0, 0, 0);
+            if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[a]) : "v"(va), "v"(vb));
+            else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc[a], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < FILL; ++q) f0 = __builtin_fmaf(f0, f1, 0.5f);
         }
@@ -50,18 +53,18 @@ __global__ __launch_bounds__(256, MINB) void cadence_kernel(unsigned long long* 
     if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int NACC, int FILL, int MINB>
+template <int NACC, int FILL, int MINB, int AGPR = 0>
 static int run(const char* name, int blocks_per_cu, int cus, unsigned long long* d_out, float* d_sink) {
     const int iters = 2000, blocks = blocks_per_cu * cus;
     CK(hipMemset(d_out, 0, (size_t)blocks * 4 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 16);      // warm-up
-    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, iters);
+    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 16);      // warm-up
+    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, iters);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)blocks * 4);
     CK(hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double sum = 0, mx = 0; for (auto v : h) { sum += (double)v; if ((double)v > mx) mx = (double)v; }
     const double per = sum / h.size() / ((double)iters * NACC), per_max = mx / ((double)iters * NACC);
-    printf("%-44s acc %d filler %d regs/launch_bounds %d blocks/CU %d: %6.1f cycles per MFMA per wave (slowest wave %6.1f)\n", name, NACC, FILL, MINB, blocks_per_cu, per, per_max);
+    printf("%-52s acc %d filler %d launch_bounds(256,%d) blocks/CU %d: %6.1f cycles per MFMA per wave (slowest wave %6.1f)\n", name, NACC, FILL, MINB, blocks_per_cu, per, per_max);
     return 0;
 }
 
@@ -72,13 +75,15 @@ int main() {
     // one wave per SIMD
     run<8, 0, 1>("1 wave/SIMD, 512-register budget", 1, cus, d_out, d_sink);
     run<8, 0, 2>("1 wave/SIMD, 256-register budget (arch VGPR acc)", 1, cus, d_out, d_sink);
+    run<8, 0, 2, 1>("1 wave/SIMD, 256-register budget, AGPR acc (asm)", 1, cus, d_out, d_sink);
     run<4, 0, 2>("1 wave/SIMD, 4 accumulators", 1, cus, d_out, d_sink);
     run<2, 0, 2>("1 wave/SIMD, 2 accumulators", 1, cus, d_out, d_sink);
     run<1, 0, 2>("1 wave/SIMD, dependent chain", 1, cus, d_out, d_sink);
     run<8, 1, 2>("1 wave/SIMD, one VALU filler per MFMA", 1, cus, d_out, d_sink);
     run<8, 2, 2>("1 wave/SIMD, two VALU fillers per MFMA", 1, cus, d_out, d_sink);
     // two waves per SIMD (two workgroups per CU, as conv3 runs)
-    run<8, 0, 2>("2 waves/SIMD", 2, cus, d_out, d_sink);
+    run<8, 0, 2>("2 waves/SIMD (arch VGPR acc)", 2, cus, d_out, d_sink);
+    run<8, 0, 2, 1>("2 waves/SIMD, AGPR acc (asm)", 2, cus, d_out, d_sink);
     run<8, 1, 2>("2 waves/SIMD, one VALU filler per MFMA", 2, cus, d_out, d_sink);
     // four waves per SIMD: needs <= 128 registers -> 4 accumulators
     run<4, 0, 4>("4 waves/SIMD, 4 accumulators", 4, cus, d_out, d_sink);
