@@ -1,0 +1,66 @@
+"""GPU twin of tests/test_host_logic.py::test_random_specs — NOT collected by default (the file name does not match test_*.py):
+run it explicitly, `python -m pytest tests/gpu_extra_random_specs.py -m gpu -q`, as tools/gpu_round3_first.sh does.  It was written
+when no GPU minutes were left to execute it; once it has passed on an MI355X it moves into tests/test_zz_widen_gpu.py.
+
+Per seed: a random layer spec / kernel sizes / channel count / quantizer / clip mode (the generator of the CPU test, wider channel
+ranges so that the conv3 / pw_se kernels take part), the HIP plan against the kernel emulation launch by launch (fp32 and bf16),
+then the facade in fp32 against the oracle with the margin rule of tests/test_parity_gpu.py."""
+import random
+
+import pytest
+import torch
+
+from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
+from oracle.restate import OracleTokenizer
+from tests.test_host_logic import _random_case
+from tests.test_parity_gpu import hip_tokenizer, run_lockstep
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = random.Random(2000 + seed)
+    kw, B, T, vcff = _random_case(rng)
+    if seed % 2:                                   # every other case at the real kernel widths
+        kw['init_dim'], kw['max_dim'] = rng.choice([32, 64]), rng.choice([128, 256])
+    return kw, B, T, vcff
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('seed', range(16))
+def test_random_specs_lockstep(seed, dtype):
+    kw, B, T, vcff = _case(seed)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=seed, randomize_se=True)
+    v = torch.randn(B, kw['channels'], T, kw['image_size'], kw['image_size'], generator=torch.Generator().manual_seed(300 + seed))
+    try:
+        run_lockstep(cfg, sd, v, dtype, headless=not vcff)
+    except AssertionError as e:
+        if 'ids differ' in str(e) and B * T * kw['image_size'] ** 2 <= 4096:
+            pytest.xfail(f'id flip on a tiny token grid (teacher-forced lockstep allows 1 %): {e}')
+        raise
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_specs_fp32_vs_oracle(seed):
+    kw, B, T, vcff = _case(seed)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=seed, randomize_se=True)
+    v = torch.randn(B, kw['channels'], T, kw['image_size'], kw['image_size'], generator=torch.Generator().manual_seed(300 + seed))
+    orc = OracleTokenizer(sd, **cfg)
+    orc.taps = {}
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+    tok = hip_tokenizer(dict(kw, use_gan=False), sd, torch.float32)
+    codes, recon = tok(v.cuda(), return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+    pre = orc.taps['prequant']
+    if kw.get('use_fsq'):
+        margin = (0.5 - (pre - pre.round()).abs()).amin(dim=-1)
+    else:
+        ncb = kw['num_codebooks']
+        margin = pre.abs().reshape(*pre.shape[:-1], ncb, -1).amin(dim=-1)
+        margin = margin.squeeze(-1) if ncb == 1 else margin
+    diff = codes.cpu() != ocodes
+    assert not (diff & (margin > 1e-4)).any(), kw
+    if not diff.any():
+        assert (recon.cpu() - orecon).abs().max().item() <= 5e-4, kw
+    assert (tok.decode_from_code_indices(ocodes.cuda(), video_contains_first_frame=vcff).cpu() - orecon).abs().max().item() <= 5e-4, kw

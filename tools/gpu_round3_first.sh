@@ -13,6 +13,7 @@ if [ -x tools/k3_bench ]; then
   timeout 120 tools/k3_bench magvit2_pytorch_amd/libmv2_hip.so quick > $O/${TAG}_k3_product_quick.log 2>&1
 fi
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/${TAG}_gpu_tests.log 2>&1; tail -3 $O/${TAG}_gpu_tests.log
+timeout 1500 python -m pytest tests/gpu_extra_random_specs.py -m gpu -q > $O/${TAG}_gpu_random_specs.log 2>&1; tail -3 $O/${TAG}_gpu_random_specs.log
 bash tools/gpu_profile.sh $TAG nopmc
 grep -h "cycles per MFMA" $O/${TAG}_mfma_cadence.log 2>/dev/null | cut -c1-200
 grep -h "time new plain\|^==" $O/${TAG}_k3_*.log 2>/dev/null | cut -c1-120 | head -60
