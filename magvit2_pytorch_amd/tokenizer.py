@@ -236,14 +236,21 @@ class VideoTokenizer(nn.Module):
         """deep copy without discriminator / VGG / multiscale discriminators, in eval mode, on the same device (reference
         :1475-1484).  Packed weights, plans and graphs are per-instance caches and are rebuilt by the copy on first use."""
         import copy
+        # the dropped modules are detached BEFORE the copy: the discriminator carries its own launcher (a ctypes library handle,
+        # device buffers, captured graphs) that must be neither copied nor pickled
+        order = list(self._modules.keys())
+        detached = {k: self._modules.pop(k) for k in ('discr', 'vgg', 'multiscale_discrs') if k in self._modules}
+        plain = {k: self.__dict__.pop(k) for k in ('discr', 'vgg') if k in self.__dict__}        # `None` placeholders are plain attributes
         ops, self._ops = self._ops, None
         self.refresh_weights()
         try:
             dup = copy.deepcopy(self)
         finally:
             self._ops = ops
-        dup._modules.pop('discr', None)
-        dup._modules.pop('vgg', None)
+            self.__dict__.update(plain)
+            self._modules.update(detached)
+            for k in order:                                       # original registration order (state_dict key order)
+                self._modules[k] = self._modules.pop(k)
         dup.discr, dup.vgg = None, None
         dup.multiscale_discrs = nn.ModuleList([])
         dup.use_gan = dup.has_gan = dup.has_multiscale_gan = dup.has_multiscale_discrs = dup.use_vgg = False
