@@ -140,7 +140,7 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 constexpr int PSETS = MV2_C3_PSETS;
 static_assert(PSETS == 2 || PSETS == 3, "position fragment sets");
 template <typename E> struct TapMma { static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) { Mma<E>::run(a, b, acc); } };
-#if MV2_C3_AGPR
+#if MV2_C3_AGPR == 1
 template <> struct TapMma<BF16> {
     static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& acc) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
@@ -336,6 +336,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         for (int bb = 0; bb < WPOS; ++bb) pset[SET][bb] = *(const i32x4*)(smem + (pbase[bb] + img) + toff);
     };
 
+#if MV2_C3_AGPR == 2
+    { float z_ = 0.f; asm volatile("; this kernel uses the accumulator file" : "+a"(z_)); }      // makes the compiler select the AGPR form of its own MFMAs
+#endif
     const int prio_par = MV2_C3_PRIO ? (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0) : 0;     // the CU's pair is (w, w + NW / 2)
     C3_PROF_DECL
     // first segment with real groups (a range may begin or end inside a tile's virtual units)
