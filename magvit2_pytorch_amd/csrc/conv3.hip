@@ -134,6 +134,12 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 // PSETS (experiments): register sets of position fragments.  3 (product) lets set (TP + 2) % 3 rest for a tap; 2 is a plain double
 // buffer (16 registers less): 9 taps per group is odd, so the fragments of the next group's first tap are moved from set 1 to
 // set 0 at the end of tap 8 (16 v_mov per group).
+// HPRO (experiments): the first halo of a segment travels in its own registers and the in-loop halo code re-derives its lane
+// values from an opaque copy of the thread id.  Needed by the AGPR form: with 128 arch VGPRs the allocator otherwise spills the
+// in-loop halo registers (scratch stores / reloads with vmcnt(0) inside the tap loop); with HPRO the tap loop has no scratch access.
+#ifndef MV2_C3_HPRO
+#define MV2_C3_HPRO 0
+#endif
 #ifndef MV2_C3_PSETS
 #define MV2_C3_PSETS 3
 #endif
@@ -258,6 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         uint32_t cur_wb, nxt_wb;
     };
     i32x4 hreg[NH];
+#if MV2_C3_HPRO
+    i32x4 hpro[NH];      // the segment's first halo travels in its own registers (live only outside the tap loop)
+#endif
     i32x4 wring[RING], pset[PSETS][WPOS];
     i32x4 bias_v;                                       // lanes 0..15 of the block: the segment's 64 bias values (part of the prefetch stream)
 
@@ -305,26 +314,68 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         const uint32_t base = (uint32_t)(((int64_t)S.ti.b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + S.hw_base;
         int r0_ = r0;
         asm volatile("" : "+v"(r0_));          // recompute the six row offsets per group: cheaper than six live registers (VGPR budget)
+#if MV2_C3_HPRO
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));        // ... and nothing lane-derived is carried through the loop in a (spillable) register
+        r0_ = tid_o >> 3;
+        const uint32_t base_h = base - (uint32_t)c * 16u + (uint32_t)(tid_o & 7) * 16u;
+#define C3_HBASE base_h
+#else
+#define C3_HBASE base
+#endif
 #pragma unroll
         for (int i = LO; i < HI; ++i) {
             const int hr = r0_ + RPP * i;
             const int hy = hr / HWD, hx = hr - hy * HWD;
             const bool ok = (S.hmask >> i) & 1u;
-            const uint32_t vo = ok ? base + (uint32_t)(hy * W_ + hx) * row_bytes : p.in_bytes;
+            const uint32_t vo = ok ? C3_HBASE + (uint32_t)(hy * W_ + hx) * row_bytes : p.in_bytes;
             hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
     };
     auto write_halo = [&](char* img, auto lo_c, auto hi_c) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#if MV2_C3_HPRO
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));
+        const int r0w = tid_w >> 3;
+        const uint32_t wr = (uint32_t)r0w * ROWP + (uint32_t)(tid_w & 7) * 16u;
+#pragma unroll
+        for (int i = LO; i < HI; ++i)
+            if (r0w + RPP * i < HR) *(i32x4*)(img + wr + i * RPP * ROWP) = hreg[i];
+#else
 #pragma unroll
         for (int i = LO; i < HI; ++i)
             if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hreg[i];
+#endif
     };
     auto issue_w1 = [&](const Seg& S, uint32_t so, int a, i32x4& dst) {
         dst = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)S.w_off0, (int)(so + (uint32_t)(a * 4096)), 0);
     };
+#if MV2_C3_HPRO
+    auto issue_halo_first = [&](const Seg& S, int chunk, int it) {
+        const int t_in = S.ti.t + it - d.pt;
+        const uint32_t base = (uint32_t)(((int64_t)S.ti.b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u + (uint32_t)c * 16u + S.hw_base;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hr = r0 + RPP * i;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const bool ok = (S.hmask >> i) & 1u;
+            const uint32_t vo = ok ? base + (uint32_t)(hy * W_ + hx) * row_bytes : p.in_bytes;
+            hpro[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
+        }
+    };
+    auto write_halo_first = [&](char* img) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hpro[i];
+    };
+#endif
     auto issue_first = [&](const Seg& S) {     // halo of the segment's first group + the first RING weight fragments + its bias values
+#if MV2_C3_HPRO
+        issue_halo_first(S, S.cur_chunk, S.cur_it);
+#else
         issue_halo(S, S.cur_chunk, S.cur_it, IC<0>{}, IC<NH>{});
+#endif
         bias_v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(tid < 16 ? (uint32_t)(S.ti.co_tile * BCO + tid * 4) * 4u : 0xfffffff0u), 0, 0);
 #pragma unroll
         for (int f = 0; f < RING; ++f) issue_w1(S, S.cur_wb + (uint32_t)(f / WCO) * tapstride, f % WCO, wring[f]);
@@ -362,7 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             for (int bb = 0; bb < WPOS; ++bb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
+#if MV2_C3_HPRO
+        write_halo_first(smem);
+#else
         write_halo(smem, IC<0>{}, IC<NH>{});
+#endif
         __syncthreads();
         read_p(0u, 0, IC<0>{});
         C3_PROF(0)

@@ -6,8 +6,9 @@ cd "$(dirname "$0")/.." || exit 1
 python3 -m magvit2_pytorch_amd.build || exit 1
 bash tools/build_c3_variants.sh \
     p3  "-DMV2_C3_PRIO=3" \
-    g2  "-DMV2_C3_AGPR=2" \
-    g2h "-DMV2_C3_AGPR=2 -DMV2_C3_HSPLIT=1 -DMV2_C3_PSETS=2" \
+    g2  "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1" \
+    g2h "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1 -DMV2_C3_HSPLIT=1 -DMV2_C3_PSETS=2" \
+    hpro "-DMV2_C3_HPRO=1" \
     ps2 "-DMV2_C3_PSETS=2" | grep -E "^==|BF16Lb0" | cut -c1-200
 /opt/rocm/bin/hipcc -w -O2 -std=c++17 tools/k3_bench.cpp -o tools/k3_bench -ldl || exit 1
 /opt/rocm/bin/hipcc -w -O3 -std=c++17 --offload-arch=gfx950 tools/mfma_cadence.cpp -o tools/mfma_cadence || exit 1
