@@ -46,6 +46,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int c = tid & 7, r0 = tid >> 3;
     const int hi = lane >> 5, l31 = lane & 31;
     CV_PROF_DECL
+#if defined(MV2_EXPERIMENTS) && defined(MV2_CONV_AGPR)
+    // experiment: a dummy use of the accumulator file switches the compiler's MFMAs to the AGPR form (C / D in a[...]); under the
+    // 256-register budget it otherwise selects the VGPR form (see conv3.hip MV2_C3_AGPR and tools/mfma_cadence.cpp)
+    { float z_ = 0.f; asm volatile("; this kernel uses the accumulator file" : "+a"(z_)); }
+#endif
 
     // ---- block -> (co tile, pos tile); XCD-aware: blocks of one XCD walk neighbouring tiles
     int bid = blockIdx.x;

@@ -8,8 +8,13 @@ python3 -m magvit2_pytorch_amd.build --experiments >/dev/null || exit 1
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -DMV2_EXPERIMENTS $defs -c $P/csrc/conv3.hip -o $P/csrc/_obj_exp/conv3_$tag.o || exit 1
-  objs=$(ls $P/csrc/_obj_exp/*.o | grep -v "/conv3" | tr '\n' ' ')
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $P/csrc/_obj_exp/conv3_$tag.o -o $P/libmv2_hip_exp_$tag.so || exit 1
+  extra=""; skip="/conv3"
+  if echo "$defs" | grep -q MV2_CONV_; then      # defines of the generic kernel: conv.hip is recompiled too
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -DMV2_EXPERIMENTS $defs -c $P/csrc/conv.hip -o $P/csrc/_obj_exp/convg_$tag.o || exit 1
+    extra=$P/csrc/_obj_exp/convg_$tag.o; skip="/conv3\|/conv\.o\|/convg_"
+  fi
+  objs=$(ls $P/csrc/_obj_exp/*.o | grep -v "$skip" | grep -v "/conv3_\|/convg_" | tr '\n' ' ')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $P/csrc/_obj_exp/conv3_$tag.o $extra -o $P/libmv2_hip_exp_$tag.so || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -DMV2_EXPERIMENTS $defs -I$R/include $P/csrc/conv3.hip -o /tmp/c3_$tag.s 2>/dev/null
   echo "== $tag ($defs)"; grep -E "^\s+\.name: +_Z|\.vgpr_count|vgpr_spill|sgpr_spill|private_segment_fixed" /tmp/c3_$tag.s | awk '{printf "%s ", $0} /vgpr_spill/{print ""}'
 done

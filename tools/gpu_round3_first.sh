@@ -11,6 +11,9 @@ if [ -x tools/k3_bench ]; then
   K3_DIST=1 timeout 60 tools/k3_bench magvit2_pytorch_amd/libmv2_hip_exp.so levels > $O/${TAG}_k3_default.log 2>&1
   for v in magvit2_pytorch_amd/libmv2_hip_exp_*.so; do [ -f "$v" ] && K3_DIST=1 timeout 60 tools/k3_bench $v levels > $O/${TAG}_k3_$(basename $v .so | sed s/libmv2_hip_exp_//).log 2>&1; done
   timeout 120 tools/k3_bench magvit2_pytorch_amd/libmv2_hip.so quick > $O/${TAG}_k3_product_quick.log 2>&1
+  # generic kernel (feed-forward / projection GEMM shapes): default tile rule only, VGPR-form against AGPR-form MFMAs
+  MV2_TILE= timeout 60 tools/k3_bench magvit2_pytorch_amd/libmv2_hip_exp.so generic 2>&1 | awk '/^---- tile 64,64/{exit} {print}' > $O/${TAG}_generic_default.log
+  [ -f magvit2_pytorch_amd/libmv2_hip_exp_cvg.so ] && MV2_TILE= timeout 60 tools/k3_bench magvit2_pytorch_amd/libmv2_hip_exp_cvg.so generic 2>&1 | awk '/^---- tile 64,64/{exit} {print}' > $O/${TAG}_generic_agpr.log
 fi
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/${TAG}_gpu_tests.log 2>&1; tail -3 $O/${TAG}_gpu_tests.log
 timeout 1500 python -m pytest tests/gpu_extra_random_specs.py -m gpu -q > $O/${TAG}_gpu_random_specs.log 2>&1; tail -3 $O/${TAG}_gpu_random_specs.log
