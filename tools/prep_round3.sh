@@ -13,4 +13,5 @@ bash tools/build_c3_variants.sh \
     ps2 "-DMV2_C3_PSETS=2" | grep -E "^==|BF16Lb0" | cut -c1-200
 /opt/rocm/bin/hipcc -w -O2 -std=c++17 tools/k3_bench.cpp -o tools/k3_bench -ldl || exit 1
 /opt/rocm/bin/hipcc -w -O3 -std=c++17 --offload-arch=gfx950 tools/mfma_cadence.cpp -o tools/mfma_cadence || exit 1
-ls -la tools/k3_bench tools/mfma_cadence magvit2_pytorch_amd/*.so | awk '{print $5, $9}'
+/opt/rocm/bin/hipcc -w -O2 -std=c++17 tools/se_bench.cpp -o tools/se_bench -ldl || exit 1
+ls -la tools/k3_bench tools/mfma_cadence tools/se_bench magvit2_pytorch_amd/*.so | awk '{print $5, $9}'
