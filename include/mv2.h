@@ -273,6 +273,13 @@ int mv2_scale_channels(int dtype, const void* x, const float* scale, void* out, 
 int mv2_copy_frames(const void* src, int src_T, int src_t0, void* dst, int dst_T, int dst_t0, int nT, int B, int64_t frame_bytes,
                     void* stream);
 
+/* Non-constant padding (CausalConv3d pad_mode 'reflect' / 'replicate' / 'circular', reference M:899-927, Conv3DMod M:750):
+ * out (B, T + pt, H + 2 ph, W + 2 pw, row) = F.pad(in (B, T, H, W, row), (pw, pw, ph, ph, pt, 0), mode) as an explicit gather of rows of
+ * row_bytes (multiple of 8) bytes; mode 1 = reflect, 2 = replicate, 3 = circular; `tail_bytes` zero bytes are written behind the image.
+ * The convolution that follows runs 'valid' (check_bounds = 0) on the padded image.  The reference's default 'constant' needs no call. */
+int mv2_pad_ndhwc(const void* in, void* out, int B, int T, int H, int W, int64_t row_bytes, int pt, int ph, int pw, int mode,
+                  int64_t tail_bytes, void* stream);
+
 /* ResidualUnit tail at C = 128 / 256 / 512, bf16: the 1x1x1 conv + bias + ELU (reference M:937-938) and the SqueezeExcite
  * pooling records of its output (reference M:226-231) in ONE launch (replaces mv2_conv k = 1 + mv2_se_pool).  `wp` is the
  * C x C kernel in mv2_conv3's fragment-major order (the 1x1x1 kernel packed as mv2_conv does, then pack.py::to_frag_major).

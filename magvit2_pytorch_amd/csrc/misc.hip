@@ -757,3 +757,47 @@ extern "C" int mv2_copy_frames(const void* src, int src_T, int src_t0, void* dst
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// --------------------------------------------------------------------------- non-constant padding (CausalConv3d pad_mode, reference M:899-927;
+// Conv3DMod M:750): F.pad(x, (pw, pw, ph, ph, pt, 0), mode) on an NDHWC tensor as an explicit gather, so that the convolution that
+// follows runs 'valid' on the padded image.  mode 1 = reflect (j < 0 -> -j, j >= n -> 2(n - 1) - j), 2 = replicate (clamp),
+// 3 = circular (j mod n); time is padded in front only.  A row is row_bytes (multiple of 8) contiguous bytes; `tail_bytes` zero bytes
+// follow the image (the conv_in gathers read 16 bytes at 8-byte alignment and may run past the last pixel).
+__device__ __forceinline__ int pad_src(int j, int n, int mode) {
+    if (mode == 1) { j = j < 0 ? -j : j; return j >= n ? 2 * (n - 1) - j : j; }
+    if (mode == 2) return min(max(j, 0), n - 1);
+    j %= n; return j < 0 ? j + n : j;
+}
+__global__ __launch_bounds__(256) void pad_ndhwc_kernel(const i32x2* __restrict__ in, i32x2* __restrict__ out, int B, int T, int H, int W, int w8,
+                                                        int pt, int ph, int pw, int mode, int64_t body, int64_t total) {
+    const int To = T + pt, Ho = H + 2 * ph, Wo = W + 2 * pw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        i32x2 v = {0, 0};
+        if (i < body) {
+            int64_t r = i / w8; const int c8 = (int)(i - r * w8);
+            const int wo = (int)(r % Wo); r /= Wo;
+            const int ho = (int)(r % Ho); r /= Ho;
+            const int to = (int)(r % To); const int64_t b = r / To;
+            const int ti = pad_src(to - pt, T, mode), hi = pad_src(ho - ph, H, mode), wi = pad_src(wo - pw, W, mode);
+            v = in[((((b * T + ti) * H + hi) * (int64_t)W + wi)) * w8 + c8];
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int mv2_pad_ndhwc(const void* in, void* out, int B, int T, int H, int W, int64_t row_bytes, int pt, int ph, int pw, int mode,
+                             int64_t tail_bytes, void* stream) {
+    if (!in || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || row_bytes <= 0 || row_bytes % 8 != 0 || tail_bytes < 0 || tail_bytes % 8 != 0) return MV2_EINVAL;
+    if (pt < 0 || ph < 0 || pw < 0 || mode < 1 || mode > 3) return MV2_EINVAL;
+    if (mode == 1 && (pt >= T || ph >= H || pw >= W)) return MV2_EINVAL;          // reflect needs padding < size (as F.pad)
+    if (mode == 3 && (pt > T || ph > H || pw > W)) return MV2_EINVAL;             // circular: padding <= size
+    if ((((uintptr_t)in | (uintptr_t)out) & 7)) return MV2_EINVAL;
+    const int64_t w8 = row_bytes / 8;
+    const int64_t body = (int64_t)B * (T + pt) * (H + 2 * ph) * (W + 2 * pw) * w8, total = body + tail_bytes / 8;
+    if (w8 > 0x7fffffff) return MV2_ETOOLARGE;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(pad_ndhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const i32x2*)in, (i32x2*)out, B, T, H, W, (int)w8, pt, ph, pw,
+                       mode, body, total);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

@@ -24,6 +24,9 @@ from . import pack as P
 from .spec import Stage, parse_layers, se_hidden, ff_inner, has_cond, cond_expanded
 
 
+PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}      # mv2_pad_ndhwc mode codes (0: no call, the gathers pad with zeros)
+
+
 class PackedModel:
     def __init__(self, cfg: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype, ops):
         self.cfg, self.dtype, self.ops = cfg, dtype, ops
@@ -575,11 +578,24 @@ class Plan:
         Hp, Wp = H + 2 * pad_hw, W + 2 * pad_hw
         tail = 64 * cp
 
-        def conv_in(name, video, frames, pad_t, To):
+        mode = PAD_MODES[cfg.get('pad_mode', 'constant')]
+
+        def conv_in(name, video, frames, pad_t, To, zero_t=0):
+            """pad_t = every frame in front of the clip: `zero_t` zero frames (the tokenizer's time_padding, M:1537) + the
+            convolution's own kt - 1, which follow pad_mode (M:925-927) like its spatial halo."""
             Tp = frames + pad_t
             padded = self.arena.get(B * Tp * Hp * Wp * cp + tail, self.dtype)
-            steps.append(ops.video_to_ndhwc(self.dt, video, padded, B, cfg['channels'], frames, H, W, pad_t, pad_hw, cp, tail))
-            self.step_names.append('video_to_ndhwc')
+            own_t = pad_t - zero_t
+            if mode and name == 'conv_in' and own_t < frames + zero_t:      # non-constant padding (M:925: constant when the clip is not longer than the time padding)
+                es = padded.element_size()
+                plain = self.arena.get(B * (frames + zero_t) * H * W * cp, self.dtype)
+                steps.append(ops.video_to_ndhwc(self.dt, video, plain, B, cfg['channels'], frames, H, W, zero_t, 0, cp, 0))
+                steps.append(ops.pad_ndhwc(plain, padded, B, frames + zero_t, H, W, cp * es, own_t, pad_hw, pad_hw, mode, tail * es))
+                self.step_names += ['video_to_ndhwc', 'pad_ndhwc']
+                self.arena.put(plain)
+            else:
+                steps.append(ops.video_to_ndhwc(self.dt, video, padded, B, cfg['channels'], frames, H, W, pad_t, pad_hw, cp, tail))
+                self.step_names.append('video_to_ndhwc')
             y = self._conv(steps, name, pm.convs[name], Act(padded, B, Tp, Hp, Wp, cp), To=To, Ho=H, Wo=W, check_bounds=False,
                            in_bytes=padded.numel() * padded.element_size())
             self.arena.put(padded)
@@ -601,7 +617,7 @@ class Plan:
             self.arena.put(ff.t)
             self.arena.put(rest.t)
         else:
-            x = conv_in('conv_in', self.video_in, T, self.time_padding + (kt - 1), T + self.time_padding)
+            x = conv_in('conv_in', self.video_in, T, self.time_padding + (kt - 1), T + self.time_padding, zero_t=self.time_padding)
         for st in pm.stages:
             x = self._stage(steps, st, st.enc_prefix, x, True)
         return x
@@ -671,11 +687,28 @@ class Plan:
             self.step_names += ['copy_frames'] * 2
             self._conv(steps, 'conv_out_first_frame', pm.convs['conv_out_first_frame'], xff, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
                        out_t=self.recon_first, out_c=4)
-            self._conv(steps, 'conv_out', pm.convs['conv_out'], xr, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
-                       out_t=self.recon_rest, out_c=4)
+            self._conv_out(steps, xr, kt, kh, kw, 0, self.recon_rest)
+            return
+        self._conv_out(steps, x, kt, kh, kw, self.time_padding, self.recon)
+
+    def _conv_out(self, steps, x: Act, kt, kh, kw, crop_t, out_t):
+        """conv_out (CausalConv3d, M:1127, 1642): zero padding comes free from out-of-range gathers; any other pad_mode is an
+        explicit gather into a padded image followed by the 'valid' convolution (M:925-927)."""
+        pm, cfg = self.pm, self.cfg
+        mode = PAD_MODES[cfg.get('pad_mode', 'constant')]
+        if mode and kt - 1 < x.T:
+            es = x.t.element_size()
+            pt_, ph_, pw_ = kt - 1, kh // 2, kw // 2
+            padded = self.arena.get(x.B * (x.T + pt_) * (x.H + 2 * ph_) * (x.W + 2 * pw_) * x.C, self.dtype)
+            steps.append(self.ops.pad_ndhwc(x.t, padded, x.B, x.T, x.H, x.W, x.C * es, pt_, ph_, pw_, mode, 0))
+            self.step_names.append('pad_ndhwc')
+            xp = Act(padded, x.B, x.T + pt_, x.H + 2 * ph_, x.W + 2 * pw_, x.C)
+            self._conv(steps, 'conv_out', pm.convs['conv_out'], xp, To=x.T, Ho=x.H, Wo=x.W, check_bounds=False, store=P.STORE_NCTHW_F32,
+                       crop_t=crop_t, out_t=out_t, out_c=4)
+            self.arena.put(padded)
             return
         self._conv(steps, 'conv_out', pm.convs['conv_out'], x, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
-                   crop_t=self.time_padding, out_t=self.recon, out_c=4)
+                   crop_t=crop_t, out_t=out_t, out_c=4)
 
     # ------------------------------------------------------------------ execution
     def run(self, steps, stream=None):

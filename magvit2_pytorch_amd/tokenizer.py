@@ -109,8 +109,8 @@ class VideoTokenizer(nn.Module):
         except Exception:
             self._configs = None
 
-        if pad_mode != 'constant':
-            raise NotImplementedError("only pad_mode='constant' (the reference default) is implemented")
+        if pad_mode not in ('constant', 'reflect', 'replicate', 'circular'):      # F.pad's modes (reference :899, 927)
+            raise ValueError(f'unknown pad_mode {pad_mode!r}')
         if lfq_spherical:
             raise NotImplementedError('lfq_spherical is not implemented')
         if not use_fsq:                                       # reference: magvit2_pytorch.py:1359
@@ -125,7 +125,7 @@ class VideoTokenizer(nn.Module):
             image_size=image_size, layers=tuple(layers), residual_conv_kernel_size=residual_conv_kernel_size,
             num_codebooks=num_codebooks, codebook_size=codebook_size, channels=channels, init_dim=init_dim, max_dim=max_dim,
             input_conv_kernel_size=tuple(input_conv_kernel_size), output_conv_kernel_size=tuple(output_conv_kernel_size),
-            lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
+            pad_mode=pad_mode, lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
             linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads, dim_cond=dim_cond,
             dim_cond_expansion_factor=dim_cond_expansion_factor, separate_first_frame_encoding=bool(separate_first_frame_encoding))

@@ -163,6 +163,11 @@ FEATURES = {
     'feat_gan_loss': dict(kw=dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual')),
                           shape=(3, 3, 5, 16, 16), wseed=5, dseed=6, discr_seed=9, pick_seed=78, ms_seeds=(1, 2), vgg_seed=3,
                           adversarial_loss_weight=0.7, multiscale_adversarial_loss_weight=0.5, perceptual_loss_weight=0.3),
+    # pad_mode != 'constant' (conv_in / conv_out, M:1109, 1127, 925-927), a clip with first frame and a headless one
+    'feat_pad_reflect': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, pad_mode='reflect', input_conv_kernel_size=(3, 5, 5),
+                                     layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=51, dseed=57),
+    'feat_pad_replicate': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, pad_mode='replicate', input_conv_kernel_size=(3, 5, 5),
+                                       layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=51, dseed=57),
     'feat_sep_loss': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
                                   layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
                           shape=(2, 3, 9, 16, 16), wseed=4, dseed=1),

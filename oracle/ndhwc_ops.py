@@ -361,6 +361,32 @@ class CpuOps:
         step.what = 'copy_frames'
         return step
 
+    def pad_ndhwc(self, x, out, B, T, H, W, row_bytes, pt, ph, pw, mode, tail_bytes):
+        """mv2_pad_ndhwc: F.pad(x, (pw, pw, ph, ph, pt, 0), mode) on an NDHWC tensor (mode 1 reflect / 2 replicate / 3 circular) + zero tail"""
+        def step(stream):
+            es = x.element_size()
+            Cc = row_bytes // es
+            src = x.reshape(-1)[: B * T * H * W * Cc].reshape(B, T, H, W, Cc)
+
+            def idx(n, lo, hi):
+                j = torch.arange(-lo, n + hi)
+                if mode == 1:
+                    j = j.abs()
+                    j = torch.where(j >= n, 2 * (n - 1) - j, j)
+                elif mode == 2:
+                    j = j.clamp(0, n - 1)
+                else:
+                    j = j % n
+                return j
+            o = src[:, idx(T, pt, 0)][:, :, idx(H, ph, ph)][:, :, :, idx(W, pw, pw)]
+            n = o.numel()
+            flat = out.reshape(-1)
+            flat[:n] = o.reshape(-1)
+            flat[n: n + tail_bytes // es] = 0
+        step.outs = [out]
+        step.what = 'pad_ndhwc'
+        return step
+
     def cond_linear(self, x, w, bias, out, B, I, O, mode, eps=1e-8):
         def step(stream):
             xv = x.reshape(-1)[: B * I].reshape(B, I).double()

@@ -50,11 +50,14 @@ def parse_layers(layers, init_dim, max_dim):
 
 
 # ----------------------------------------------------------------------------- blocks
-def causal_conv3d(x, w, b, stride=1):
-    """M:892-928: front-pad time by (kt-1) + (1-stride), same-pad H/W, constant zeros."""
+def causal_conv3d(x, w, b, stride=1, pad_mode='constant'):
+    """M:892-928: front-pad time by (kt-1) + (1-stride), same-pad H/W; `pad_mode` as F.pad's mode (the reference default is
+    constant zeros; the tokenizer passes its pad_mode to conv_in and conv_out only, M:1109, 1127), falling back to constant
+    when the clip is not longer than the time padding (M:925)."""
     kt, kh, kw = w.shape[2:]
     tp = (kt - 1) + (1 - stride)
-    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, tp, 0))
+    mode = pad_mode if tp < x.shape[2] else 'constant'
+    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, tp, 0), mode=mode)
     return F.conv3d(x, w, b, stride=(stride, 1, 1))
 
 
@@ -346,7 +349,7 @@ class OracleTokenizer:
     def __init__(self, state_dict, *, image_size, layers, codebook_size=None, init_dim=64, max_dim=float('inf'),
                  channels=3, num_codebooks=1, use_fsq=False, fsq_levels=None, attn_dim_head=32, attn_heads=8,
                  linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10., dim_cond=None,
-                 separate_first_frame_encoding=False, dtype=torch.float32, **_ignored):
+                 separate_first_frame_encoding=False, pad_mode='constant', dtype=torch.float32, **_ignored):
         self.p = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone())
                   for k, v in state_dict.items() if not k.startswith('discr.')}
         self.dtype = dtype
@@ -364,6 +367,7 @@ class OracleTokenizer:
         self.time_padding = self.time_downsample_factor - 1
         self.fmap_size = image_size // (2 ** sum(s['kind'] == 'compress_space' for s in self.stages))
         self.separate_first_frame = bool(separate_first_frame_encoding)
+        self.pad_mode = pad_mode
         self.dim_cond = dim_cond
         self.has_cond = any(st['kind'].startswith('cond_') for st in self.stages)
         self.taps = None            # optional dict name -> tensor for layer-wise debugging
@@ -424,12 +428,12 @@ class OracleTokenizer:
             # padding starts right before frame 1 — it never sees the first frame), then time_padding zero frames in front
             w2 = self.p['conv_in_first_frame.weight']
             ff = F.conv2d(x[:, :, 0], w2, self.p['conv_in_first_frame.bias'], padding=(w2.shape[-2] // 2, w2.shape[-1] // 2))
-            rest = causal_conv3d(x[:, :, 1:], self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias'])
+            rest = causal_conv3d(x[:, :, 1:], self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias'], pad_mode=self.pad_mode)
             x = torch.cat((ff.unsqueeze(2), rest), dim=2)
             x = self._tap('conv_in', F.pad(x, (0, 0, 0, 0, self.time_padding, 0)))
         else:
             x = F.pad(x, (0, 0, 0, 0, tp, 0))                                   # M:1534-1537
-            x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias']))
+            x = self._tap('conv_in', causal_conv3d(x, self.p['conv_in.conv.weight'], self.p['conv_in.conv.bias'], pad_mode=self.pad_mode))
         ce = self._cond_in(cond, 'encoder_cond_in')
         for i, st in enumerate(self.stages):
             x = self._tap(f'enc{i}', self._stage(x, st, f'encoder_layers.{i}', True, cond=ce))
@@ -459,9 +463,9 @@ class OracleTokenizer:
             tp = self.time_padding
             w2 = self.p['conv_out_first_frame.weight']
             outff = F.conv2d(x[:, :, tp], w2, self.p['conv_out_first_frame.bias'], padding=(w2.shape[-2] // 2, w2.shape[-1] // 2))
-            out = causal_conv3d(x[:, :, tp + 1:], self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
+            out = causal_conv3d(x[:, :, tp + 1:], self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'], pad_mode=self.pad_mode)
             return torch.cat((outff.unsqueeze(2), out), dim=2)
-        x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'])
+        x = causal_conv3d(x, self.p['conv_out.conv.weight'], self.p['conv_out.conv.bias'], pad_mode=self.pad_mode)
         return x[:, :, self.time_padding:] if video_contains_first_frame else x  # M:1646-1647
 
     def decode_from_code_indices(self, codes, cond=None, video_contains_first_frame=True):

@@ -64,3 +64,28 @@ def test_random_specs_fp32_vs_oracle(seed):
     if not diff.any():
         assert (recon.cpu() - orecon).abs().max().item() <= 5e-4, kw
     assert (tok.decode_from_code_indices(ocodes.cuda(), video_contains_first_frame=vcff).cpu() - orecon).abs().max().item() <= 5e-4, kw
+
+
+# ------------------------------------------------------------------------------- pad_mode (mv2_pad_ndhwc: a kernel written without GPU access)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('pad_mode', ['reflect', 'replicate', 'circular'])
+def test_pad_mode_lockstep_and_fixture(pad_mode, dtype):
+    """mv2_pad_ndhwc against the emulation launch by launch (conv_in with 8-byte pixels and a tail, conv_out with 32-byte rows), then the
+    facade in fp32 against the reference's own output (tests/golden/feat_pad_*.npz) where a fixture exists."""
+    import numpy as np
+    from tests._util import Feature
+    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, pad_mode=pad_mode, input_conv_kernel_size=(3, 5, 5),
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=61, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(62))
+    run_lockstep(cfg, sd, v, dtype)
+    run_lockstep(cfg, sd, v[:, :, :4], dtype, headless=True)
+    if dtype == torch.float32 and pad_mode in ('reflect', 'replicate'):
+        f = Feature(f'feat_pad_{pad_mode}')
+        tok = hip_tokenizer(dict(f.kw, use_gan=False), f.weights(), torch.float32)
+        codes, recon = tok(f.video().cuda(), return_codes=True, return_recon=True)
+        want = torch.from_numpy(np.asarray(f.z['codes']))
+        assert (codes.cpu() != want).float().mean().item() <= 0.005
+        if torch.equal(codes.cpu(), want):
+            assert (recon.cpu() - torch.from_numpy(np.asarray(f.z['recon']))).abs().max().item() <= 5e-4

@@ -52,6 +52,11 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
                 kt=3, kh=3, kw=3, nsteps=27, seg_bytes=128, check_bounds=1, act=1, store=0, rt=1, rh=1, rw=1, crop_t=0, out_c=64,
                 splitk=0)
     d = ops_hip.ConvDesc(**good)
+    # mv2_pad_ndhwc: null pointers, unknown mode, rows that are not whole 8-byte words, reflect padding >= size (as F.pad), misaligned tail
+    assert lib.mv2_pad_ndhwc(None, ptr, 1, 4, 8, 8, 16, 2, 1, 1, 1, 0, None) == EINVAL
+    for args in ((1, 4, 8, 8, 16, 2, 1, 1, 0, 0), (1, 4, 8, 8, 16, 2, 1, 1, 4, 0), (1, 4, 8, 8, 12, 2, 1, 1, 1, 0), (1, 2, 8, 8, 16, 2, 1, 1, 1, 0),
+                 (1, 4, 8, 8, 16, 2, 8, 1, 1, 0), (1, 4, 8, 8, 16, 2, 1, 1, 2, 4), (0, 4, 8, 8, 16, 2, 1, 1, 2, 0)):
+        assert lib.mv2_pad_ndhwc(ptr, ptr, *args, None) == EINVAL, args
     # null pointers
     assert lib.mv2_conv(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, 0, None) == EINVAL
     assert lib.mv2_conv3(ctypes.byref(d), None, 0, None, None, None, None, 1, None, 0.0, None, None, None, 0, None, 0, None) == EINVAL
@@ -500,7 +505,7 @@ def test_facade_vs_reference_feature_fixtures():
             total, br = tok(f.video(), return_loss=True)
             assert abs(float(total) - f.scalar(f'{mode}_total')) <= 1e-5 * max(1., abs(f.scalar(f'{mode}_total'))), (name, mode)
             assert abs(float(br.lfq_aux_loss) - f.scalar(f'{mode}_aux')) <= 1e-5
-    for name in ('feat_cond_residual', 'feat_sep_first_frame'):
+    for name in ('feat_cond_residual', 'feat_sep_first_frame', 'feat_pad_reflect', 'feat_pad_replicate'):
         f = Feature(name)
         tok = emulated_tokenizer(dict(f.kw, use_gan=False), f.weights(), torch.float32)
         ckw = dict(cond=f.cond()) if f.cond() is not None else {}
@@ -794,3 +799,33 @@ def test_random_specs(seed):
     if not diff.any():
         assert (recon - orecon).abs().max().item() <= 2e-5, kw
     assert (tok.decode_from_code_indices(ocodes, video_contains_first_frame=vcff) - orecon).abs().max().item() <= 2e-5, kw
+
+
+# ------------------------------------------------------------------------------- pad_mode
+@pytest.mark.parametrize('pad_mode', ['reflect', 'replicate', 'circular'])
+@pytest.mark.parametrize('sep', [False, True])
+def test_pad_mode_matches_oracle(pad_mode, sep):
+    """pad_mode reaches conv_in and conv_out only (reference :1109, 1127): mv2_pad_ndhwc gathers the padded image, the convolution runs
+    'valid' on it; constant padding when the clip is not longer than the time padding (:925), which the T = 1 image case exercises."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, pad_mode=pad_mode, separate_first_frame_encoding=sep,
+              input_conv_kernel_size=(3, 5, 5), output_conv_kernel_size=(3, 3, 3),
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=51, randomize_se=True)
+    orc = OracleTokenizer(sd, **cfg)
+    for dtype, tol in ((torch.float32, 5e-6), (torch.bfloat16, None)):
+        tok = emulated_tokenizer(kw, sd, dtype)
+        for frames, vcff in ((5, True), (4, False)) + (((1, True),) if not sep else ()):
+            v = torch.randn(2, 3, frames, 16, 16, generator=torch.Generator().manual_seed(52 + frames))
+            ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+            codes, recon = tok(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+            if tol is not None:
+                assert torch.equal(codes, ocodes), (pad_mode, frames)
+                assert (recon - orecon).abs().max().item() <= tol
+                assert (tok.decode_from_code_indices(ocodes, video_contains_first_frame=vcff) - orecon).abs().max().item() <= tol
+            else:
+                assert (codes != ocodes).float().mean().item() <= 0.05 and (recon - orecon).abs().mean().item() <= 2e-2
+    names = tok._plan(2, 5)[0].step_names
+    assert names.count('pad_ndhwc') == 2                                   # conv_in and conv_out, nothing else
+    with pytest.raises(ValueError):
+        VideoTokenizer(image_size=16, codebook_size=64, layers=('residual',), pad_mode='mirror')

@@ -340,3 +340,28 @@ def test_identity_projections_match_reference(kw):
     ocodes, orecon = orc(v, return_codes=True, return_recon=True)
     assert ocodes.dtype == codes.dtype and torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
     assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
+
+
+# ------------------------------------------------------------------------------- pad_mode (conv_in / conv_out only, M:1109, 1127)
+@pytest.mark.parametrize('pad_mode', ['reflect', 'replicate', 'circular'])
+@pytest.mark.parametrize('sep', [False, True])
+def test_pad_mode_matches_reference(pad_mode, sep):
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, pad_mode=pad_mode, separate_first_frame_encoding=sep,
+              input_conv_kernel_size=(3, 5, 5), output_conv_kernel_size=(3, 3, 3),
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=51, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    orc = OracleTokenizer(sd, **cfg)
+    for frames, vcff in ((5, True), (4, False), (1, True)) if not sep else ((5, True), (4, False)):
+        v = torch.randn(2, 3, frames, 16, 16, generator=torch.Generator().manual_seed(52 + frames))
+        with torch.no_grad():
+            codes, recon = ref(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+        ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+        assert torch.equal(ocodes, codes), (pad_mode, frames)
+        assert torch.allclose(orecon, recon, atol=1e-5, rtol=0), (pad_mode, frames)
+    # the mode matters: the constant-padded model gives other ids on a clip longer than the time padding
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(57))
+    oc_mode, oc_const = orc(v, return_codes=True), OracleTokenizer(sd, **dict(cfg, pad_mode='constant'))(v, return_codes=True)
+    assert (oc_const != oc_mode).float().mean().item() > 0.1
