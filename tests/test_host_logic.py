@@ -829,3 +829,26 @@ def test_pad_mode_matches_oracle(pad_mode, sep):
     assert names.count('pad_ndhwc') == 2                                   # conv_in and conv_out, nothing else
     with pytest.raises(ValueError):
         VideoTokenizer(image_size=16, codebook_size=64, layers=('residual',), pad_mode='mirror')
+
+
+def test_harness_tools_compile(tmp_path):
+    """tools/k3_bench.cpp, tools/se_bench.cpp (host harnesses over the C ABI) and tools/mfma_cadence.cpp (gfx950 micro-benchmark) are the
+    cheap way to iterate kernels on a GPU box (~15 s of budget per run): keep them compiling.  se_bench's CPU reference is also run
+    (GPU-free --dump mode) and checked against the Python oracle."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else None)
+    if hipcc is None:
+        pytest.skip('hipcc not available')
+    for src, extra in (('k3_bench.cpp', ['-ldl']), ('se_bench.cpp', ['-ldl']), ('mfma_cadence.cpp', ['--offload-arch=gfx950'])):
+        out = str(tmp_path / src.replace('.cpp', ''))
+        r = subprocess.run([hipcc, '-w', '-O1', '-std=c++17', os.path.join(ROOT, 'tools', src), '-o', out, *extra], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    lib = os.path.join(ROOT, 'magvit2_pytorch_amd', 'libmv2_hip.so')
+    d = tmp_path / 'dump'
+    d.mkdir()
+    r = subprocess.run([str(tmp_path / 'se_bench'), lib, '--dump', str(d)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_se_bench_reference.py'), str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
