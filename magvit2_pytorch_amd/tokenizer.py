@@ -185,6 +185,8 @@ class VideoTokenizer(nn.Module):
         from .discriminator import Discriminator
         dk = dict(discr_kwargs) if _exists(discr_kwargs) else dict(dim=stages[-1].dim_out if stages else init_dim, image_size=image_size,
                                                                   channels=channels, max_dim=512)
+        if self.use_gan and channels > 4:
+            raise NotImplementedError(f'channels={channels} with use_gan: the image discriminator reads 4-channel pixels; pass use_gan=False')
         self.discr = Discriminator(**dk, seed=(seed + 1) if seed is not None else None) if self.use_gan else None
 
         self.compute_dtype: Optional[torch.dtype] = None      # None = infer (see module docstring)
@@ -198,10 +200,11 @@ class VideoTokenizer(nn.Module):
 
     @staticmethod
     def _validate_widths(channels, stages):
-        """Channel widths the kernels support: conv_in packs <= 4 input channels per pixel; rows are moved in
+        """Channel widths the kernels support: conv_in packs <= 8 input channels per pixel (4-channel pixels up to 4 channels,
+        8-channel pixels above; the image discriminator reads 4-channel pixels, so use_gan needs channels <= 4); rows are moved in
         16-byte chunks (8 bf16), RMSNorm / TokenShift kernels split rows into power-of-two lane groups."""
-        if channels > 4:
-            raise NotImplementedError(f'channels={channels}: the input convolution packs at most 4 channels per pixel')
+        if channels > 8:
+            raise NotImplementedError(f'channels={channels}: the input convolution packs at most 8 channels per pixel')
         pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
         for st in stages:
             for dim in {st.dim, st.dim_out}:

@@ -89,3 +89,13 @@ def test_pad_mode_lockstep_and_fixture(pad_mode, dtype):
         assert (codes.cpu() != want).float().mean().item() <= 0.005
         if torch.equal(codes.cpu(), want):
             assert (recon.cpu() - torch.from_numpy(np.asarray(f.z['recon']))).abs().max().item() <= 5e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('channels', [1, 5, 8])
+def test_input_channel_counts_lockstep(channels, dtype):
+    """8-channel input pixels (5 .. 8 channels): the round-1 conv_in layout, not exercised by the default suite of round 2"""
+    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, channels=channels, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=63, randomize_se=True)
+    run_lockstep(cfg, sd, torch.randn(2, channels, 5, 32, 32, generator=torch.Generator().manual_seed(64)), dtype)

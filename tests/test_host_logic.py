@@ -262,9 +262,23 @@ def test_squeeze_excite_forms_agree(monkeypatch):
 def test_unsupported_widths_are_rejected_at_construction():
     """widths the kernels cannot run must fail in the constructor with a clear message, not as an opaque
     error code at the first forward."""
-    for bad in (dict(channels=5), dict(init_dim=12), dict(init_dim=24, layers=('attend_space',))):
+    for bad in (dict(channels=9), dict(channels=5, use_gan=True), dict(init_dim=12), dict(init_dim=24, layers=('attend_space',))):
         with pytest.raises(NotImplementedError):
-            VideoTokenizer(image_size=32, codebook_size=256, **{**dict(init_dim=8, max_dim=64, layers=README_LAYERS), **bad})
+            VideoTokenizer(image_size=32, codebook_size=256, **{**dict(init_dim=8, max_dim=64, layers=README_LAYERS, use_gan=False), **bad})
+
+
+@pytest.mark.parametrize('channels', [1, 4, 5, 8])
+def test_input_channel_counts_match_oracle(channels):
+    """1 .. 4 channels travel as 4-channel pixels, 5 .. 8 as 8-channel pixels (conv_in's (iw, c) K extent); conv_out stores `channels` planes."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, channels=channels, input_conv_kernel_size=(3, 5, 5),
+              layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    tok = emulated_tokenizer(dict(kw, use_gan=False), sd, torch.float32)
+    v = torch.randn(2, channels, 5, 16, 16, generator=torch.Generator().manual_seed(4))
+    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    assert torch.equal(codes, ocodes) and recon.shape == v.shape and (recon - orecon).abs().max().item() <= 5e-6
 
 
 def test_plan_cache_is_bounded():

@@ -365,3 +365,17 @@ def test_pad_mode_matches_reference(pad_mode, sep):
     v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(57))
     oc_mode, oc_const = orc(v, return_codes=True), OracleTokenizer(sd, **dict(cfg, pad_mode='constant'))(v, return_codes=True)
     assert (oc_const != oc_mode).float().mean().item() > 0.1
+
+
+def test_six_input_channels_match_reference():
+    """channels outside {1, 3, 4}: the reference takes any count (no VGG then, M:1392); pins the oracle for the 8-channel pixel path."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, channels=6, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 6, 5, 16, 16, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
+    assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
