@@ -58,6 +58,15 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+class MagViT2(nn.Module):
+    """The reference's top-level export of the same name is an identity placeholder (magvit2_pytorch.py:1900-1905: `forward(x)` returns x);
+    kept so that `from magvit2_pytorch import MagViT2, VideoTokenizer` keeps working after the one-line swap of INTEGRATION.md §1.
+    (`VideoTokenizerTrainer` is training machinery around the path and is not provided.)"""
+
+    def forward(self, x):
+        return x
+
+
 class VideoTokenizer(nn.Module):
     def __init__(
         self,
