@@ -140,6 +140,13 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 #ifndef MV2_C3_HPRO
 #define MV2_C3_HPRO 0
 #endif
+// LATEPF (experiments, for the AGPR form): where the next segment's first halo / weights / bias are requested.  0 (product): behind the
+// cross-wave reduce, so that they land under the ticket and the epilogue — 52 registers live across those phases, which the 128 arch
+// VGPRs of the AGPR form cannot hold (the loaded halo is spilled to scratch and reloaded: ~100 spill slots).  1: after the epilogue.
+// 2: at the top of the next segment, nothing loop-carried in registers (27 spill slots left, none inside the tap loop).
+#ifndef MV2_C3_LATEPF
+#define MV2_C3_LATEPF 0
+#endif
 #ifndef MV2_C3_PSETS
 #define MV2_C3_PSETS 3
 #endif
@@ -403,8 +410,13 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     };
     Seg S;
     if (!next_seg(x0, S)) { C3_PROF_END return; }
+#if MV2_C3_LATEPF != 2
     issue_first(S);
+#endif
     for (;;) {
+#if MV2_C3_LATEPF == 2
+        issue_first(S);      // experiment: no prefetch across the segment boundary (nothing loop-carried in registers between segments)
+#endif
         C3_PROF(4)
         f32x16 acc[WCO][WPOS];
 #pragma unroll
@@ -519,7 +531,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
         // registers of the loads are free until the next tap loop): they land under this segment's ticket / epilogue
         Seg N = S;
         const bool has_next = next_seg(S.xe, N);
+#if MV2_C3_LATEPF
+        // experiment (AGPR form, 128 arch VGPRs): the next segment's prefetch waits until the epilogue has released its registers
+#else
         if (has_next) issue_first(N);
+#endif
         C3_PROF(2)
 
         // ---- a tile cut by a range boundary: publish the partial, take a ticket, the last arriver sums every part.
@@ -701,6 +717,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             }
         }
         if (!has_next) break;
+#if MV2_C3_LATEPF == 1
+        issue_first(N);
+#endif
         C3_SUB(5)
         __syncthreads();                                    // every wave left its private tile: LDS becomes the halo image again
         C3_SUB(6)

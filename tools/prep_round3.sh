@@ -8,6 +8,7 @@ bash tools/build_c3_variants.sh \
     p3  "-DMV2_C3_PRIO=3" \
     g2  "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1" \
     g2h "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1 -DMV2_C3_HSPLIT=1 -DMV2_C3_PSETS=2" \
+    g2l "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1 -DMV2_C3_LATEPF=2" \
     hpro "-DMV2_C3_HPRO=1" \
     cvg "-DMV2_CONV_AGPR=1" \
     ps2 "-DMV2_C3_PSETS=2" | grep -E "^==|BF16Lb0" | cut -c1-200
