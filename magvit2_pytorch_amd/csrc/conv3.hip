@@ -2,24 +2,27 @@
 // :892-928; ~81 % of the path's FLOPs), optionally fused with the unit's 1x1x1 conv + ELU (:938-940) and the
 // SqueezeExcite pooling partials (:226-231).
 //
-// Decomposition (gfx950: 256 CUs, 4 SIMDs per CU, 512 registers per lane at one wave per SIMD):
-//   * ONE 4-wave workgroup per CU.  A block owns a BCO x (TH x TW) output tile (128co x 8x16 or 64co x 16x16);
-//     the four waves split K: wave w multiplies k-slice w (16 of the 64 channels of every 128-byte chunk) of EVERY
-//     tap and keeps the whole tile in its own 256 accumulator registers (4x4 or 2x8 MFMA tiles of 32x32).  A wave
-//     therefore issues 16 MFMAs per 8 (or 10) operand fragments, and no two waves share a weight byte:
+// Decomposition (gfx950: 256 CUs, 4 SIMDs per CU, 512 registers per lane per SIMD):
+//   * TWO 4-wave workgroups per CU (256 registers per wave).  A workgroup owns a 64-channel x 8x16-position output tile;
+//     its four waves split K: wave w multiplies k-slice w (16 of the 64 channels of every 128-byte chunk) of EVERY
+//     tap and keeps the whole tile in its own 128 accumulator registers (2 x 4 MFMA tiles of 32x32).  A wave
+//     therefore issues 8 MFMAs per 6 operand fragments, and no two waves share a weight byte:
 //   * weights never touch LDS: they are packed on the host in MFMA-fragment order
-//     ([step][co/32][k-slice][lane][16 B], pack.py frag_major) and each wave streams its own 1 KB fragments
-//     global -> VGPR, three taps ahead;
-//   * only the (TH+2) x (TW+2) input halo of one (frame, chunk) lives in LDS (double buffered, XOR-swizzled
-//     128-byte rows); the nine spatial taps are nine row offsets into it.  One barrier per NINE taps;
-//   * the four partial tiles are reduced through LDS once per tile (fixed order -> deterministic);
+//     ([step][co/32][k-slice][half][row][16 B], pack.py frag_major) and each wave streams its own 1 KB fragments
+//     global -> VGPR through a ring of slots, three taps ahead;
+//   * only the 10 x 18 input halo of one (frame, chunk) lives in LDS (double buffered, 144-byte padded rows, odd tile
+//     rows rotated: conflict-free); the nine spatial taps are nine immediate offsets into it.  One barrier per NINE taps;
+//   * the four partial tiles are reduced through LDS once per tile (fixed order -> deterministic); afterwards every wave
+//     owns all 64 channels of its 32 positions and runs its epilogue without a block barrier;
 //   * groups (chunk, time tap) whose input frame lies in the causal zero padding are skipped, not multiplied;
-//   * stream-K: the grid is one block per CU; block w walks the contiguous range [w G/W, (w+1) G/W) of the
-//     tile-major list of all G groups, so every CU gets the same number of 9-tap groups (no tail at batch 1).  A
-//     tile cut by a range boundary is finished in-kernel: every part drops its fp32 partial into a slab, takes a
+//   * stream-K: worker w walks the contiguous range [w G/W, (w+1) G/W) of the tile-major list of all G cost-weighted
+//     units.  A tile cut by a range boundary is finished in-kernel: every part drops its fp32 partial into a slab, takes a
 //     ticket, and the LAST arriver sums all parts in part order (bitwise deterministic) and runs the epilogue
-//     (agent-scope release / acquire as cdna_hip_programming.md §6 G16 prescribes; no spinning, so no residency
-//     requirement).  There is no finish kernel and no second pass over the output.
+//     (write-through sc1 stores / loads, cdna_hip_programming.md §5; no spinning, so no residency requirement).  Where a
+//     worker owns >= 4 tiles the range ends are snapped to tile starts instead and nothing is cut.  There is no finish
+//     kernel and no second pass over the output.
+// What limits it (measured, profiles/r02_k3_findings.md): one wave per SIMD issues an MFMA every ~49 cycles here whatever its
+// loads do; the MV2_C3_* macros below are the experiment variants of tools/build_c3_variants.sh (experiments build only).
 // Zero padding in space comes from out-of-range buffer offsets (hardware returns 0).
 #include <algorithm>
 #include <cstdlib>
