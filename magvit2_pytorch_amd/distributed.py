@@ -109,3 +109,26 @@ def reconstruction_metrics_sharded(tokenizer, video: torch.Tensor) -> Dict[str, 
     tot = reduce_metrics(dict(se=se, n=n), device=tokenizer.device if on_gpu else None)
     mse = tot['se'] / max(tot['n'], 1.0)
     return dict(mse=mse, psnr=float('inf') if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item())
+
+
+@torch.no_grad()
+def discriminator_metrics_sharded(tokenizer, video: torch.Tensor) -> Dict[str, float]:
+    """Global-batch hinge discriminator loss and mean logits over a sharded batch (the "discriminator / metrics reduction" of the
+    brief): every rank runs forward(return_discr_loss=True, apply_gradient_penalty=False) on its clips — one random frame per clip
+    through the image discriminator (reference magvit2_pytorch.py:1730-1750) — and contributes per-clip SUMS; one all_reduce of four
+    scalars.  The hinge loss is a mean over clips, so sum / count reproduces the single-process value on the whole batch for the
+    same frame picks; empty shards contribute zeros and still join the collective."""
+    local = shard_batch(video)
+    on_gpu = tokenizer.device.type == 'cuda'
+    sums = dict(hinge=0.0, real=0.0, fake=0.0, n=0.0)
+    if local.shape[0] > 0:
+        dev_in = local.to(tokenizer.device) if on_gpu else local
+        total, br = tokenizer(dev_in, return_discr_loss=True, apply_gradient_penalty=False)
+        n = float(local.shape[0])
+        sums = dict(hinge=float(br.discr_loss) * n, n=n, real=0.0, fake=0.0)
+        lg = getattr(tokenizer, '_last_discr_logits', None)
+        if lg is not None:
+            sums.update(real=float(lg[0].sum()), fake=float(lg[1].sum()))
+    tot = reduce_metrics(sums, device=tokenizer.device if on_gpu else None)
+    n = max(tot['n'], 1.0)
+    return dict(discr_loss=tot['hinge'] / n, real_logits_mean=tot['real'] / n, fake_logits_mean=tot['fake'] / n, clips=tot['n'])

@@ -577,6 +577,7 @@ class VideoTokenizer(nn.Module):
             return out[0].clone()
 
         discr_loss = hinge(fake_logits, real_logits)
+        self._last_discr_logits = (real_logits.detach().float().reshape(-1), fake_logits.detach().float().reshape(-1))      # for metrics reductions
         zero = torch.zeros((), device=discr_loss.device)
         ms = [zero]
         if self.has_multiscale_discrs:

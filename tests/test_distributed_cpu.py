@@ -131,3 +131,58 @@ def test_two_rank_lfq_aux_loss_is_the_global_batch_loss():
         assert abs(recon - float(part['recon_loss'])) <= 1e-5
         assert abs(total - (recon + aux)) <= 1e-6
     assert res[0][3] == res[1][3]                                    # identical on both ranks
+
+
+# ------------------------------------------------------------------------------- discriminator / metrics reduction across ranks
+GAN_KW = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
+
+
+def _gan_tok():
+    tok = VideoTokenizer(**GAN_KW, use_gan=True, perceptual_loss_weight=0., seed=0)
+    tok.load_state_dict(init_state_dict(make_cfg(**GAN_KW), seed=0, randomize_se=True))
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    return tok
+
+
+def _discr_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    D.init_from_env('gloo')
+    tok = _gan_tok()
+    video = torch.randn(total, 3, 5, 16, 16, generator=torch.Generator().manual_seed(3))
+    torch.manual_seed(100 + rank)                       # the frame pick draws from the CPU default generator (reference :1736)
+    q.put((rank, D.discriminator_metrics_sharded(tok, video)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [3, 1])      # ragged (2 + 1) and one empty shard
+def test_two_rank_discriminator_metrics(total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_discr_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected: the clip-weighted mean of the per-shard losses, each with its rank's frame picks
+    tok = _gan_tok()
+    video = torch.randn(total, 3, 5, 16, 16, generator=torch.Generator().manual_seed(3))
+    hinge = real = fake = 0.
+    for r in range(2):
+        lo, hi = D.shard_bounds(total, r, 2)
+        if hi > lo:
+            torch.manual_seed(100 + r)
+            _, br = tok(video[lo:hi], return_discr_loss=True, apply_gradient_penalty=False)
+            hinge += float(br.discr_loss) * (hi - lo)
+            real += float(tok._last_discr_logits[0].sum())
+            fake += float(tok._last_discr_logits[1].sum())
+    for r in range(2):
+        m = res[r]
+        assert m['clips'] == total and abs(m['discr_loss'] - hinge / total) <= 1e-6
+        assert abs(m['real_logits_mean'] - real / total) <= 1e-6 and abs(m['fake_logits_mean'] - fake / total) <= 1e-6
+    assert res[0] == res[1]
