@@ -10,6 +10,7 @@ bash tools/build_c3_variants.sh \
     g2h "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1 -DMV2_C3_HSPLIT=1 -DMV2_C3_PSETS=2" \
     g2l "-DMV2_C3_AGPR=2 -DMV2_C3_HPRO=1 -DMV2_C3_LATEPF=2" \
     hpro "-DMV2_C3_HPRO=1" \
+    oq "-DMV2_C3_OWNQ=1" \
     cvg "-DMV2_CONV_AGPR=1" \
     ps2 "-DMV2_C3_PSETS=2" | grep -E "^==|BF16Lb0" | cut -c1-200
 /opt/rocm/bin/hipcc -w -O2 -std=c++17 tools/k3_bench.cpp -o tools/k3_bench -ldl || exit 1
