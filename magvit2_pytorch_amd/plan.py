@@ -260,13 +260,18 @@ class Plan:
         self.ids = ops.empty((x.rows, pm.ncb), torch.int32 if pm.use_fsq else torch.int64)
         self.prequant = ops.empty((x.rows, pm.cb_dim * pm.ncb), torch.float32) if want_prequant else None
         q = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
+        # lfq_spherical (third-party LFQ(spherical=True), reference M:1070, 1372): input and quantized value are l2-normalised per
+        # codebook.  Normalising keeps every sign, so the ids are those of the plain quantizer and the quantized value is
+        # +-1/sqrt(cb_dim) per code dim: the eval path is the same kernel with that scale.  (The training-mode statistics would need
+        # the normalised activations: refused by the facade.)
+        self.lfq_scale = pm.cb_dim ** -0.5 if (self.cfg.get('lfq_spherical') and not pm.use_fsq) else 1.
         if pm.use_fsq:
             self.q_steps.append(ops.fsq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, self.ids,
                                         self.prequant, x.rows, x.C, pm.cb_dim, pm.ncb))
         else:
             fwd = ops.lfq_train if self.train else ops.lfq
             self.q_steps.append(fwd(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, q.t, self.ids, self.prequant,
-                                    x.rows, x.C, pm.cb_dim, pm.ncb, self.cfg['lfq_soft_clamp_input_value'] or 0., 1.))
+                                    x.rows, x.C, pm.cb_dim, pm.ncb, self.cfg['lfq_soft_clamp_input_value'] or 0., self.lfq_scale))
         self.quantized = q
         # ---- losses (forward(return_loss=True), reference M:1705-1722): per-rank sums on device; the facade all-reduces
         # `lfq_sums` across ranks before the finalising launch
@@ -298,7 +303,7 @@ class Plan:
         if pm.use_fsq:
             self.codes_steps = [ops.fsq_codes(self.dt, self.ids_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, x.rows, x.C, pm.cb_dim, pm.ncb)]
         else:
-            self.codes_steps = [ops.lfq_codes(self.dt, self.ids_in, pm.q_w_out, pm.q_b_out, q.t, x.rows, x.C, pm.cb_dim, pm.ncb, 1.)]
+            self.codes_steps = [ops.lfq_codes(self.dt, self.ids_in, pm.q_w_out, pm.q_b_out, q.t, x.rows, x.C, pm.cb_dim, pm.ncb, self.lfq_scale)]
         # ---- decode
         self.dec_steps: List = []
         self._lower_decode(self.dec_steps, q)

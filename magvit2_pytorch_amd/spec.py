@@ -267,7 +267,7 @@ DEFAULT_CFG = dict(
     channels=3, init_dim=64, max_dim=float('inf'), input_conv_kernel_size=(7, 7, 7), output_conv_kernel_size=(3, 3, 3),
     pad_mode='constant', lfq_soft_clamp_input_value=10., use_fsq=False, fsq_levels=None, attn_dim_head=32,
     attn_heads=8, linear_attn_dim_head=8, linear_attn_heads=16, dim_cond=None, dim_cond_expansion_factor=4.,
-    separate_first_frame_encoding=False,
+    separate_first_frame_encoding=False, lfq_spherical=False,
 )
 
 README_LAYERS = (

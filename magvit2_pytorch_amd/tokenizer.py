@@ -120,8 +120,6 @@ class VideoTokenizer(nn.Module):
 
         if pad_mode not in ('constant', 'reflect', 'replicate', 'circular'):      # F.pad's modes (reference :899, 927)
             raise ValueError(f'unknown pad_mode {pad_mode!r}')
-        if lfq_spherical:
-            raise NotImplementedError('lfq_spherical is not implemented')
         if not use_fsq:                                       # reference: magvit2_pytorch.py:1359
             assert _exists(codebook_size) and not _exists(fsq_levels), \
                 'if use_fsq is set to False, `codebook_size` must be set (and not `fsq_levels`)'
@@ -137,7 +135,8 @@ class VideoTokenizer(nn.Module):
             pad_mode=pad_mode, lfq_soft_clamp_input_value=lfq_soft_clamp_input_value, use_fsq=use_fsq,
             fsq_levels=list(fsq_levels) if _exists(fsq_levels) else None, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
             linear_attn_dim_head=linear_attn_dim_head, linear_attn_heads=linear_attn_heads, dim_cond=dim_cond,
-            dim_cond_expansion_factor=dim_cond_expansion_factor, separate_first_frame_encoding=bool(separate_first_frame_encoding))
+            dim_cond_expansion_factor=dim_cond_expansion_factor, separate_first_frame_encoding=bool(separate_first_frame_encoding),
+            lfq_spherical=bool(lfq_spherical) and not use_fsq)
         self.has_cond = S.has_cond(self.cfg)
         self.dim_cond = dim_cond
         if self.has_cond:
@@ -596,6 +595,9 @@ class VideoTokenizer(nn.Module):
         discriminator's kernels (M:1826-1832), adaptive weight 1.  Perceptual term: the caller's `vgg` module on one random frame
         pair per sample (M:1785-1805), drawn first, as in the reference."""
         train = self.training and not self.use_fsq
+        if train and self.cfg.get('lfq_spherical'):
+            raise NotImplementedError('training-mode auxiliary loss with lfq_spherical: the entropy / commitment statistics need the l2-normalised '
+                                      'activations, which the statistics kernel does not produce; eval mode (aux loss 0) is served')
         if train and self.cfg['codebook_size'] > 4096:
             raise NotImplementedError('the training-mode entropy loss enumerates the codebook per token; mv2_lfq_stats supports '
                                       'codebook_size <= 4096 per codebook (use eval mode, or more codebooks of <= 12 bits)')

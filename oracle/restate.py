@@ -256,19 +256,25 @@ def _code_dtype(p):
     return torch.float32 if w is None else w.dtype
 
 
-def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1., train=False):
-    """third-party LFQ.forward eval path (reconstruction; see oracle/thirdparty.py)."""
+def lfq_quantize(x, p, codebook_dim, num_codebooks=1, clamp=10., scale=1., train=False, spherical=False):
+    """third-party LFQ.forward eval path (reconstruction; see oracle/thirdparty.py).  spherical: the projected input and the
+    quantized value are l2-normalised per codebook (ids unchanged: normalisation keeps every sign; quantized = +-scale / sqrt(d))."""
     B, C = x.shape[:2]
     sp = x.shape[2:]
     tok = x.reshape(B, C, -1).transpose(1, 2)
     z = _project(tok, p, 'project_in')
     if clamp is not None:
         z = (z / clamp).tanh() * clamp
-    z = z.reshape(B, -1, num_codebooks, codebook_dim).float()
+    z = z.reshape(B, -1, num_codebooks, codebook_dim)
+    if spherical:
+        z = F.normalize(z, dim=-1) * scale
+    z = z.float()
     pos = z > 0
     mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
     ids = (pos.int() * mask).sum(dim=-1)                                       # int64
     q = torch.where(pos, torch.full_like(z, scale), torch.full_like(z, -scale))
+    if spherical:
+        q = F.normalize(q, dim=-1) * scale
     if train:
         q = z + (q - z)                                                        # straight-through value (forward: q up to fp32 rounding)
     q = q.to(x.dtype).reshape(B, -1, num_codebooks * codebook_dim)
@@ -299,14 +305,16 @@ def lfq_train_losses(z, codebook_dim, num_codebooks, inv_temperature=100., diver
     return per_sample, batch, commit, aux
 
 
-def lfq_indices_to_codes(ids, p, codebook_dim, num_codebooks=1, scale=1.):
+def lfq_indices_to_codes(ids, p, codebook_dim, num_codebooks=1, scale=1., spherical=False):
     dtype = _code_dtype(p)
     if num_codebooks == 1:
         ids = ids.unsqueeze(-1)
     mask = (2 ** torch.arange(codebook_dim - 1, -1, -1)).int()
     bits = ((ids[..., None].int() & mask) != 0).to(dtype)
-    codes = (bits * scale * 2 - scale).flatten(-2)
-    out = _project(codes, p, 'project_out')
+    codes = bits * scale * 2 - scale
+    if spherical:
+        codes = F.normalize(codes, dim=-1) * scale
+    out = _project(codes.flatten(-2), p, 'project_out')
     return out.movedim(-1, 1)
 
 
@@ -349,7 +357,7 @@ class OracleTokenizer:
     def __init__(self, state_dict, *, image_size, layers, codebook_size=None, init_dim=64, max_dim=float('inf'),
                  channels=3, num_codebooks=1, use_fsq=False, fsq_levels=None, attn_dim_head=32, attn_heads=8,
                  linear_attn_dim_head=8, linear_attn_heads=16, lfq_soft_clamp_input_value=10., dim_cond=None,
-                 separate_first_frame_encoding=False, pad_mode='constant', dtype=torch.float32, **_ignored):
+                 separate_first_frame_encoding=False, pad_mode='constant', lfq_spherical=False, dtype=torch.float32, **_ignored):
         self.p = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone())
                   for k, v in state_dict.items() if not k.startswith('discr.')}
         self.dtype = dtype
@@ -368,6 +376,7 @@ class OracleTokenizer:
         self.fmap_size = image_size // (2 ** sum(s['kind'] == 'compress_space' for s in self.stages))
         self.separate_first_frame = bool(separate_first_frame_encoding)
         self.pad_mode = pad_mode
+        self.lfq_spherical = bool(lfq_spherical)
         self.dim_cond = dim_cond
         self.has_cond = any(st['kind'].startswith('cond_') for st in self.stages)
         self.taps = None            # optional dict name -> tensor for layer-wise debugging
@@ -443,14 +452,14 @@ class OracleTokenizer:
         if self.use_fsq:
             q, ids, pre = fsq_quantize(x, self.p, self.fsq_levels)
         else:
-            q, ids, pre = lfq_quantize(x, self.p, self.codebook_dim, self.num_codebooks, self.clamp, train=train)
+            q, ids, pre = lfq_quantize(x, self.p, self.codebook_dim, self.num_codebooks, self.clamp, train=train, spherical=self.lfq_spherical)
         self._tap('prequant', pre)
         return self._tap('quantized', q), ids
 
     def indices_to_codes(self, ids):
         if self.use_fsq:
             return fsq_indices_to_codes(ids, self.p, self.fsq_levels)
-        return lfq_indices_to_codes(ids, self.p, self.codebook_dim, self.num_codebooks)
+        return lfq_indices_to_codes(ids, self.p, self.codebook_dim, self.num_codebooks, spherical=self.lfq_spherical)
 
     def decode(self, q, cond=None, video_contains_first_frame=True):
         """M:1597-1649 (headless: nothing is cropped, M:1646)."""
@@ -524,7 +533,8 @@ class OracleTokenizer:
             zero = recon_loss.new_zeros(())
             if train:
                 ps, bt, cm, aux = lfq_train_losses(self.taps['prequant'], self.codebook_dim, self.num_codebooks, diversity_gamma=lfq_diversity_gamma,
-                                                   entropy_loss_weight=lfq_entropy_loss_weight, commitment_loss_weight=lfq_commitment_loss_weight)
+                                                   entropy_loss_weight=lfq_entropy_loss_weight, commitment_loss_weight=lfq_commitment_loss_weight,
+                                                   scale=self.codebook_dim ** -0.5 if self.lfq_spherical else 1.)
             else:
                 ps = bt = cm = aux = zero
             batch, frames = video.shape[0], video.shape[2]

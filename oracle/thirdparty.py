@@ -95,7 +95,11 @@ class LFQ(nn.Module):
         codebook_dims = codebook_dim * num_codebooks
         dim = dim if dim is not None else codebook_dims
         has_projections = has_projections if has_projections is not None else dim != codebook_dims
-        assert not cosine_sim_project_in and not spherical, 'not restated (unused by the scoped configs)'
+        assert not cosine_sim_project_in, 'not restated (unused by the scoped configs)'
+        # spherical (RECONSTRUCTION from memory of upstream, parity unpinned like the rest of this class): inputs, quantized values, code
+        # book and looked-up codes are l2-normalised per codebook and multiplied by codebook_scale: `maybe_l2norm`
+        self.spherical = spherical
+        self.maybe_l2norm = (lambda t: F.normalize(t, dim=-1) * self.codebook_scale) if spherical else (lambda t: t)
 
         self.project_in = nn.Linear(dim, codebook_dims, bias=projection_has_bias) if has_projections else nn.Identity()
         self.project_out = nn.Linear(codebook_dims, dim, bias=projection_has_bias) if has_projections else nn.Identity()
@@ -131,6 +135,7 @@ class LFQ(nn.Module):
             indices = indices.unsqueeze(-1)
         bits = ((indices[..., None].int() & self.mask) != 0).to(self.dtype)
         codes = bits * self.codebook_scale * 2 - self.codebook_scale
+        codes = self.maybe_l2norm(codes)
         codes = codes.flatten(-2)                      # '... c d -> ... (c d)'
         if project_out:
             codes = self.project_out(codes)
@@ -156,18 +161,20 @@ class LFQ(nn.Module):
             x = (x / v).tanh() * v
         b, n, _ = x.shape
         x = x.reshape(b, n, self.num_codebooks, self.codebook_dim)
+        x = self.maybe_l2norm(x)
         orig_dtype = x.dtype
         x = x.float()
         codebook_value = torch.ones_like(x) * self.codebook_scale
         quantized = torch.where(x > 0, codebook_value, -codebook_value)
         indices = ((quantized > 0).int() * self.mask.int()).sum(dim=-1)   # int64, 'b n c'
+        quantized = self.maybe_l2norm(quantized)
         per_sample_entropy = batch_entropy = commit_loss = entropy_aux_loss = self.zero
         if self.training:
             original_input = x
             x = x + (quantized - x).detach()                                  # straight-through estimator
             all_codes = torch.arange(self.codebook_size, device=x.device)
             bits = ((all_codes[..., None].int() & self.mask.int()) != 0).float()
-            codebook = bits * self.codebook_scale * 2 - self.codebook_scale   # (K, d): every sign pattern, MSB first
+            codebook = self.maybe_l2norm(bits * self.codebook_scale * 2 - self.codebook_scale)   # (K, d): every sign pattern, MSB first
             distance = -2 * torch.einsum('...id,jd->...ij', original_input, codebook)
             prob = (-distance * inv_temperature).softmax(dim=-1)              # (b, n, c, K)
             prob = prob.reshape(b * n, self.num_codebooks, self.codebook_size)

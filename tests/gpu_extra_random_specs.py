@@ -99,3 +99,20 @@ def test_input_channel_counts_lockstep(channels, dtype):
     cfg = make_cfg(**kw)
     sd = init_state_dict(cfg, seed=63, randomize_se=True)
     run_lockstep(cfg, sd, torch.randn(2, channels, 5, 32, 32, generator=torch.Generator().manual_seed(64)), dtype)
+
+
+def test_lfq_spherical_fp32_vs_oracle():
+    """eval-mode lfq_spherical: the LFQ kernels with scale = 1/sqrt(code dims) (a value of `scale` the default suite never passes)"""
+    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, lfq_spherical=True, layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=65, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(66))
+    run_lockstep(cfg, sd, v, torch.float32)
+    run_lockstep(cfg, sd, v, torch.bfloat16)
+    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
+    tok = hip_tokenizer(dict(kw, use_gan=False), sd, torch.float32)
+    codes, recon = tok(v.cuda(), return_codes=True, return_recon=True)
+    assert (codes.cpu() != ocodes).float().mean().item() <= 0.005
+    if torch.equal(codes.cpu(), ocodes):
+        assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
+    assert (tok.decode_from_code_indices(ocodes.cuda()).cpu() - orecon).abs().max().item() <= 5e-4

@@ -866,3 +866,30 @@ def test_harness_tools_compile(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_se_bench_reference.py'), str(d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('ncb', [1, 2])
+def test_lfq_spherical_matches_oracle(ncb):
+    """eval-mode lfq_spherical = the plain kernels with the quantized value scaled to 1/sqrt(code dims) (the l2 normalisation of a sign
+    vector; the ids do not change).  Training-mode statistics need the normalised activations: refused."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, num_codebooks=ncb, lfq_spherical=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=9, randomize_se=True)
+    orc = OracleTokenizer(sd, **cfg)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(10))
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    tok = VideoTokenizer(**kw, use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok.load_state_dict(sd)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    assert torch.equal(codes, ocodes) and (recon - orecon).abs().max().item() <= 5e-6
+    assert (tok.decode_from_code_indices(ocodes) - orecon).abs().max().item() <= 5e-6
+    tok.eval()
+    total, br = tok(v, return_loss=True)                              # eval mode: aux loss 0, as the reference
+    want, _ = orc.forward_loss(v, training=False)
+    assert abs(float(total) - float(want)) <= 1e-5 and float(br.lfq_aux_loss) == 0.
+    tok.train()
+    with pytest.raises(NotImplementedError):
+        tok(v, return_loss=True)

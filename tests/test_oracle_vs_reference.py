@@ -379,3 +379,31 @@ def test_six_input_channels_match_reference():
         codes, recon = ref(v, return_codes=True, return_recon=True)
     ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
     assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize('ncb', [1, 2])
+def test_lfq_spherical_matches_reference(ncb):
+    """lfq_spherical (M:1070, 1372 -> third-party LFQ(spherical=True)).  The third-party arithmetic is a RECONSTRUCTION here as for the plain LFQ
+    (oracle/thirdparty.py, parity unpinned): what this pins is the restated path against the reference's own control flow around it — eval
+    ids / reconstruction / decode-from-ids and the training-mode loss scalars."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, num_codebooks=ncb, lfq_spherical=True,
+              layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=9, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(10))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+        dec = ref.decode_from_code_indices(codes)
+        ref.train()
+        total, br = ref(v, return_loss=True)
+    orc = OracleTokenizer(sd, **cfg)
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
+    assert torch.allclose(orc.decode_from_code_indices(codes), dec, atol=1e-5, rtol=0)
+    ototal, d = orc.forward_loss(v, training=True)
+    assert torch.allclose(ototal, total, atol=2e-6, rtol=1e-5) and torch.allclose(d['aux'], torch.as_tensor(br.lfq_aux_loss).float(), atol=2e-6, rtol=1e-5)
+    # normalisation keeps every sign: the ids are those of the plain quantizer, the reconstruction is not
+    pcodes, precon = OracleTokenizer(sd, **dict(cfg, lfq_spherical=False))(v, return_codes=True, return_recon=True)
+    assert torch.equal(pcodes, ocodes) and (precon - orecon).abs().max().item() > 1e-2
