@@ -262,8 +262,9 @@ class Plan:
         q = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
         # lfq_spherical (third-party LFQ(spherical=True), reference M:1070, 1372): input and quantized value are l2-normalised per
         # codebook.  Normalising keeps every sign, so the ids are those of the plain quantizer and the quantized value is
-        # +-1/sqrt(cb_dim) per code dim: the eval path is the same kernel with that scale.  (The training-mode statistics would need
-        # the normalised activations: refused by the facade.)
+        # +-1/sqrt(cb_dim) per code dim: the eval path is the same kernel with that scale.  The training-mode statistics read the
+        # NORMALISED activations with the same scale: the facade normalises `prequant` (rows x code dims, a few KB) between the forward
+        # launches and mv2_lfq_stats.
         self.lfq_scale = pm.cb_dim ** -0.5 if (self.cfg.get('lfq_spherical') and not pm.use_fsq) else 1.
         if pm.use_fsq:
             self.q_steps.append(ops.fsq(self.dt, x.t, pm.q_w_in, pm.q_b_in, pm.q_w_out, pm.q_b_out, pm.fsq, q.t, self.ids,
@@ -296,7 +297,7 @@ class Plan:
             self.lfq_sums = ops.empty((pm.ncb * K + 2,), torch.float32)
             self.lfq_losses = ops.empty((4,), torch.float32)
             st_ws = ops.empty((max(1, ops.lfq_stats_workspace_bytes(x.rows, pm.cb_dim, pm.ncb) // 4),), torch.float32)
-            self.loss_steps.append(ops.lfq_stats(self.prequant, x.rows, pm.cb_dim, pm.ncb, self.cfg.get('lfq_inv_temperature', 100.), 1.,
+            self.loss_steps.append(ops.lfq_stats(self.prequant, x.rows, pm.cb_dim, pm.ncb, self.cfg.get('lfq_inv_temperature', 100.), self.lfq_scale,
                                                  self.lfq_sums, st_ws))
         # ---- ids -> quantized (decode_from_code_indices)
         self.ids_in = ops.empty((x.rows, pm.ncb), torch.int32 if pm.use_fsq else torch.int64)

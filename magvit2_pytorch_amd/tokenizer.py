@@ -595,16 +595,24 @@ class VideoTokenizer(nn.Module):
         discriminator's kernels (M:1826-1832), adaptive weight 1.  Perceptual term: the caller's `vgg` module on one random frame
         pair per sample (M:1785-1805), drawn first, as in the reference."""
         train = self.training and not self.use_fsq
-        if train and self.cfg.get('lfq_spherical'):
-            raise NotImplementedError('training-mode auxiliary loss with lfq_spherical: the entropy / commitment statistics need the l2-normalised '
-                                      'activations, which the statistics kernel does not produce; eval mode (aux loss 0) is served')
         if train and self.cfg['codebook_size'] > 4096:
             raise NotImplementedError('the training-mode entropy loss enumerates the codebook per token; mv2_lfq_stats supports '
                                       'codebook_size <= 4096 per codebook (use eval mode, or more codebooks of <= 12 bits)')
         plan, key = self._plan(video.shape[0], video.shape[2], train=train, headless=not vcff)
         self._set_video(plan, video)
         self._set_cond(plan, cond, video.shape[0])
-        self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
+        if train and self.cfg.get('lfq_spherical'):
+            # third-party LFQ(spherical=True): entropy / commitment statistics are taken on the l2-normalised activations (and the
+            # normalised code book = the kernels' `scale`).  The forward launches leave the projected activations in `prequant`
+            # (rows x code dims fp32, a few KB): they are normalised per codebook here, between the forward and the statistics launch.
+            nr = plan.n_recon_steps
+            self._run(plan, key, 'fwd+recon', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps[:nr]])
+            pm = plan.pm
+            z = plan.prequant[: plan.n_tokens].reshape(plan.n_tokens, pm.ncb, pm.cb_dim)
+            z.copy_(torch.nn.functional.normalize(z, dim=-1))
+            plan.run(plan.loss_steps[nr:])
+        else:
+            self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
         recon_loss = self._recon_loss(plan)
         zero = torch.zeros((), device=recon_loss.device)
         if train:

@@ -10,6 +10,7 @@ import random
 import pytest
 import torch
 
+from magvit2_pytorch_amd import VideoTokenizer
 from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
 from oracle.restate import OracleTokenizer
 from tests.test_host_logic import _random_case
@@ -116,3 +117,11 @@ def test_lfq_spherical_fp32_vs_oracle():
     if torch.equal(codes.cpu(), ocodes):
         assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
     assert (tok.decode_from_code_indices(ocodes.cuda()).cpu() - orecon).abs().max().item() <= 5e-4
+    tok2 = VideoTokenizer(**kw, use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok2.load_state_dict(sd)
+    tok2 = tok2.cuda()
+    tok2.compute_dtype = torch.float32
+    tok2.train()
+    total, br = tok2(v.cuda(), return_loss=True)
+    want, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=True)
+    assert abs(float(total) - float(want)) <= 3e-4 * max(1., abs(float(want))) and abs(float(br.lfq_aux_loss) - float(d['aux'])) <= 3e-4
