@@ -148,6 +148,7 @@ class VideoTokenizer(nn.Module):
                 raise ValueError('cond_attend_space / cond_attend_time need dim_cond_expansion_factor=1 (AdaptiveRMSNorm is built '
                                  'on dim_cond, the cond stems emit dim_cond * dim_cond_expansion_factor)')
 
+        self.attn_dropout = float(attn_dropout)      # reference :1230-1296: dropout inside the attention layers, active in training mode only
         self.use_gan = bool(use_gan)
         self.perceptual_loss_weight = float(perceptual_loss_weight)
         self.quantizer_aux_loss_weight = float(quantizer_aux_loss_weight)
@@ -594,6 +595,9 @@ class VideoTokenizer(nn.Module):
         rank, as in the reference.  With a GAN: -mean(D(one random reconstructed frame per sample)) through the image
         discriminator's kernels (M:1826-1832), adaptive weight 1.  Perceptual term: the caller's `vgg` module on one random frame
         pair per sample (M:1785-1805), drawn first, as in the reference."""
+        if self.training and self.attn_dropout > 0.:
+            raise NotImplementedError('attn_dropout > 0 in training mode draws random attention masks (reference Attend, attend.py:60, 213); the '
+                                      'kernels have no dropout: call in eval mode or construct with attn_dropout=0.')
         train = self.training and not self.use_fsq
         if train and self.cfg['codebook_size'] > 4096:
             raise NotImplementedError('the training-mode entropy loss enumerates the codebook per token; mv2_lfq_stats supports '

@@ -896,3 +896,18 @@ def test_lfq_spherical_matches_oracle(ncb):
     assert abs(float(total) - float(want)) <= 1e-5 * max(1., abs(float(want))) and abs(float(br.lfq_aux_loss) - float(d['aux'])) <= 1e-5
     qb = br.quantizer_loss_breakdown
     assert abs(float(qb.commitment) - float(d['commitment'])) <= 1e-5 and abs(float(qb.per_sample_entropy) - float(d['per_sample_entropy'])) <= 1e-5
+
+
+def test_attention_dropout_is_refused_in_training_mode_only():
+    """attn_dropout is inactive in eval mode (the hot path); a training-mode loss with dropout would need random masks"""
+    tok = VideoTokenizer(image_size=16, init_dim=16, max_dim=16, codebook_size=64, layers=('residual', 'attend_space'), attn_dropout=0.1,
+                         use_gan=False, perceptual_loss_weight=0., seed=0)
+    tok._set_backend(CpuOps())
+    tok.compute_dtype = torch.float32
+    v = torch.randn(1, 3, 1, 16, 16, generator=torch.Generator().manual_seed(0))
+    tok.eval()
+    tok(v, return_codes=True)
+    tok(v, return_loss=True)
+    tok.train()
+    with pytest.raises(NotImplementedError):
+        tok(v, return_loss=True)
