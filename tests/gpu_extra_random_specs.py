@@ -125,3 +125,16 @@ def test_lfq_spherical_fp32_vs_oracle():
     total, br = tok2(v.cuda(), return_loss=True)
     want, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=True)
     assert abs(float(total) - float(want)) <= 3e-4 * max(1., abs(float(want))) and abs(float(br.lfq_aux_loss) - float(d['aux'])) <= 3e-4
+
+
+@pytest.mark.parametrize('depth', [1, 2, 3])
+def test_tokenize_stream_on_gpu(depth):
+    """uploads and id downloads on a side stream, compute on the current stream: same ids, in order, as clip-by-clip tokenize()"""
+    from magvit2_pytorch_amd.streaming import tokenize_stream
+    from tests._util import Golden
+    g = Golden('small_lfq')
+    tok = hip_tokenizer(g.kw, g.weights(), torch.bfloat16)
+    clips = [torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(80 + i)).pin_memory() for i in range(7)]
+    want = [tok.tokenize(v.cuda()).cpu() for v in clips]
+    got = list(tokenize_stream(tok, clips, depth=depth))
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))

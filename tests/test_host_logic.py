@@ -911,3 +911,16 @@ def test_attention_dropout_is_refused_in_training_mode_only():
     tok.train()
     with pytest.raises(NotImplementedError):
         tok(v, return_loss=True)
+
+
+def test_tokenize_stream_matches_plain_loop():
+    """streaming.tokenize_stream (uploads / downloads on a side stream on the GPU) yields, in order, what tokenize() gives clip by clip;
+    on the CPU backend it is the plain loop, which is what this checks — the stream / event choreography has a GPU twin in
+    tests/gpu_extra_random_specs.py."""
+    from magvit2_pytorch_amd.streaming import tokenize_stream
+    g = Golden('small_lfq')
+    tok = emulated_tokenizer(g.kw, g.weights(), torch.float32)
+    clips = [torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(70 + i)) for i in range(4)]
+    got = list(tokenize_stream(tok, clips, depth=2))
+    assert len(got) == 4 and all(torch.equal(a, tok.tokenize(v)) for a, v in zip(got, clips))
+    assert list(tokenize_stream(tok, [], depth=3)) == []
