@@ -22,6 +22,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // compiler otherwise picks the VGPR form of the MFMA: C / D in arch VGPRs, .agpr_count 0)
 template <int NACC, int FILL, int MINB, int AGPR = 0>
 __global__ __launch_bounds__(256, MINB) void cadence_kernel(unsigned long long* out, float* sink, int iters) {
+    extern __shared__ char lds_pad[];      // dynamic LDS only pins the residency: 96 / 64 / 36 KB per block -> exactly 1 / 2 / 4 blocks per CU
+    if (iters < 0) sink[1] = lds_pad[threadIdx.x];
     f32x16 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -56,9 +58,11 @@ __global__ __launch_bounds__(256, MINB) void cadence_kernel(unsigned long long* 
 template <int NACC, int FILL, int MINB, int AGPR = 0>
 static int run(const char* name, int blocks_per_cu, int cus, unsigned long long* d_out, float* d_sink) {
     const int iters = 2000, blocks = blocks_per_cu * cus;
+    const int lds = blocks_per_cu == 1 ? 96 * 1024 : (blocks_per_cu == 2 ? 64 * 1024 : 36 * 1024);
+    CK(hipFuncSetAttribute((const void*)cadence_kernel<NACC, FILL, MINB, AGPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(d_out, 0, (size_t)blocks * 4 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 16);      // warm-up
-    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), 0, 0, d_out, d_sink, iters);
+    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), lds, 0, d_out, d_sink, 16);      // warm-up
+    hipLaunchKernelGGL((cadence_kernel<NACC, FILL, MINB, AGPR>), dim3(blocks), dim3(256), lds, 0, d_out, d_sink, iters);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)blocks * 4);
     CK(hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
