@@ -280,6 +280,12 @@ int mv2_copy_frames(const void* src, int src_T, int src_t0, void* dst, int dst_T
 int mv2_pad_ndhwc(const void* in, void* out, int B, int T, int H, int W, int64_t row_bytes, int pt, int ph, int pw, int mode,
                   int64_t tail_bytes, void* stream);
 
+/* 'gateloop_time' (reference M:1216-1222 -> third-party gateloop_transformer.SimpleGateLoopLayer, a reconstruction: parity unpinned).
+ * qkva: rows (B, T, P) x 3C = [q | kv | a], the Linear(dim, 3 dim) of the RMS-normed tokens (mv2_conv with rowscale).  Per pixel and
+ * channel along time: h_t = sigmoid(a_t) h_{t-1} + kv_t (h_{-1} = 0), out_t = q_t h_t + residual_t (the Residual wrapper, M:167-174).
+ * out may alias residual. */
+int mv2_gateloop_scan(int dtype, const void* qkva, const void* residual, void* out, int B, int T, int64_t P, int C, void* stream);
+
 /* ResidualUnit tail at C = 128 / 256 / 512, bf16: the 1x1x1 conv + bias + ELU (reference M:937-938) and the SqueezeExcite
  * pooling records of its output (reference M:226-231) in ONE launch (replaces mv2_conv k = 1 + mv2_se_pool).  `wp` is the
  * C x C kernel in mv2_conv3's fragment-major order (the 1x1x1 kernel packed as mv2_conv does, then pack.py::to_frag_major).

@@ -801,3 +801,53 @@ extern "C" int mv2_pad_ndhwc(const void* in, void* out, int B, int T, int H, int
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// --------------------------------------------------------------------------- gate loop along time ('gateloop_time', reference M:1216-1222 ->
+// third-party gateloop_transformer.SimpleGateLoopLayer; RECONSTRUCTION, parity unpinned: the package is absent from /root/reference)
+// qkva rows (B, T, P) x 3C = [q | kv | a] of Linear(dim, 3 dim) on the RMS-normed tokens; per pixel and channel, along time:
+//     h_t = sigmoid(a_t) * h_{t-1} + kv_t   (h_{-1} = 0),     out_t = q_t * h_t + residual_t          (Residual, M:167-174)
+// One thread owns one 16-byte channel chunk of one pixel and walks its T steps; consecutive threads read consecutive chunks.
+template <typename E>
+__global__ __launch_bounds__(256) void gateloop_scan_kernel(const void* __restrict__ qkva, const void* __restrict__ res, void* __restrict__ out,
+                                                            int64_t nseq, int T, int64_t P, int C) {
+    constexpr int KV = E::kVec;
+    const int cpr = C / KV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nseq * cpr; i += (int64_t)gridDim.x * 256) {
+        const int64_t seq = i / cpr;                 // (b, p)
+        const int ch = (int)(i - seq * cpr);
+        const int64_t b = seq / P, p = seq - b * P;
+        float h[8];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) h[k] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int64_t row = (b * T + t) * P + p;
+            const i32x4* qr = (const i32x4*)qkva + row * (3 * cpr);
+            float q[8], kv[8], a[8], r[8];
+            Chunk<E>::unpack(qr[ch], q);
+            Chunk<E>::unpack(qr[cpr + ch], kv);
+            Chunk<E>::unpack(qr[2 * cpr + ch], a);
+            Chunk<E>::unpack(((const i32x4*)res)[row * cpr + ch], r);
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const float g = 1.f / (1.f + expf(-a[k]));
+                h[k] = g * h[k] + kv[k];
+                r[k] += q[k] * h[k];
+            }
+            ((i32x4*)out)[row * cpr + ch] = Chunk<E>::pack(r);
+        }
+    }
+}
+
+extern "C" int mv2_gateloop_scan(int dtype, const void* qkva, const void* residual, void* out, int B, int T, int64_t P, int C, void* stream) {
+    if (!qkva || !residual || !out || B <= 0 || T <= 0 || P <= 0) return MV2_EINVAL;
+    if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    const int kvec = dtype == MV2_BF16 ? 8 : 4;
+    if (C <= 0 || C % kvec != 0) return MV2_EINVAL;
+    const int64_t nseq = (int64_t)B * P, total = nseq * (C / kvec);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((gateloop_scan_kernel<BF16>), dim3(blocks), dim3(256), 0, st, qkva, residual, out, nseq, T, P, C);
+    else hipLaunchKernelGGL((gateloop_scan_kernel<F32>), dim3(blocks), dim3(256), 0, st, qkva, residual, out, nseq, T, P, C);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

@@ -58,6 +58,7 @@ _SIGS = {
     'mv2_pack_conv3d_bytes': (C.c_size_t, [C.c_int] * 6),
     'mv2_pack_conv3d': (C.c_int, [C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_size_t]),
     'mv2_copy_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    'mv2_gateloop_scan': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     'mv2_pad_ndhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     'mv2_cond_linear': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     'mv2_scale_channels': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -197,6 +198,10 @@ class HipOps:
     def copy_frames(self, src, src_T, src_t0, dst, dst_T, dst_t0, nT, B, frame_bytes):
         fn, args = self.lib.mv2_copy_frames, (_ptr(src), src_T, src_t0, _ptr(dst), dst_T, dst_t0, nT, B, frame_bytes)
         return _mk(fn, args, 'mv2_copy_frames', (src, dst), [dst])
+
+    def gateloop_scan(self, dt, qkva, residual, out, B, T, Pn, Cc):
+        fn, args = self.lib.mv2_gateloop_scan, (dt, _ptr(qkva), _ptr(residual), _ptr(out), B, T, Pn, Cc)
+        return _mk(fn, args, 'mv2_gateloop_scan', (qkva, residual, out), [out])
 
     def pad_ndhwc(self, x, out, B, T, H, W, row_bytes, pt, ph, pw, mode, tail_bytes):
         fn, args = self.lib.mv2_pad_ndhwc, (_ptr(x), _ptr(out), B, T, H, W, row_bytes, pt, ph, pw, mode, tail_bytes)

@@ -134,6 +134,9 @@ class PackedModel:
                 elif st.kind == 'attend_time':
                     attention(pre + '.0.fn.fn', st.dim, True)
                     feed_forward(pre + '.1.fn.fn', st.dim, True)
+                elif st.kind == 'gateloop_time':
+                    g = f(pre + '.fn.fn.norm.gamma') * (st.dim ** 0.5)
+                    put(pre + '.fn.fn.qkva', P.pack_pointwise(f(pre + '.fn.fn.to_qkva.0.weight'), None, dtype, in_scale=g))
                 elif st.kind == 'cond_residual':
                     residual_unit_mod(pre)
                 elif st.kind == 'cond_attend_space':
@@ -549,6 +552,21 @@ class Plan:
         self.arena.put(x.t)
         return out
 
+    def _gateloop(self, steps, pre, x: Act) -> Act:
+        """'gateloop_time' (reference M:1216-1222; third-party SimpleGateLoopLayer, reconstruction): RMSNorm folded into the Linear
+        (gamma * sqrt(dim) in the weights, 1 / |x| as the epilogue rowscale), [q | kv | a] = one pointwise GEMM, then the gated
+        scan along time with the residual add (mv2_gateloop_scan)."""
+        pm, ops = self.pm, self.ops
+        rs = self._rms(steps, x, False)
+        qkva = self._conv(steps, pre + '.qkva', pm.convs[pre + '.qkva'], x, rowscale=rs, check_bounds=False)
+        self.arena.put(rs)
+        out = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
+        steps.append(ops.gateloop_scan(self.dt, qkva.t, x.t, out.t, x.B, x.T, x.H * x.W, x.C))
+        self.step_names.append('gateloop_scan')
+        self.arena.put(qkva.t)
+        self.arena.put(x.t)
+        return out
+
     def _linear_attention(self, steps, pre, x: Act) -> Act:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['linear_attn_heads'], cfg['linear_attn_dim_head']
@@ -661,6 +679,8 @@ class Plan:
         if st.kind == 'attend_time':
             x = self._attention(steps, pre + '.0.fn.fn', x, True)
             return self._feed_forward(steps, pre + '.1.fn.fn', x, True)
+        if st.kind == 'gateloop_time':
+            return self._gateloop(steps, pre + '.fn.fn', x)
         cond = self.cond_e if enc else self.cond_d
         if st.kind == 'cond_residual':
             return self._residual_unit_mod(steps, pre, x, cond)

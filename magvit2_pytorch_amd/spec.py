@@ -26,9 +26,9 @@ from typing import List, Tuple
 import torch
 
 SCOPED = ('residual', 'consecutive_residual', 'compress_space', 'compress_time',
-          'attend_space', 'linear_attend_space', 'attend_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time')
+          'attend_space', 'linear_attend_space', 'attend_time', 'gateloop_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time')
 COND = ('cond_residual', 'cond_attend_space', 'cond_attend_time')
-UNSCOPED = ('cond_linear_attend_space', 'gateloop_time')
+UNSCOPED = ('cond_linear_attend_space',)
 
 
 @dataclass
@@ -185,6 +185,11 @@ def param_specs(cfg) -> List[ParamSpec]:
             elif st.kind == 'linear_attend_space':
                 sp += _linear_attention(pre + '.0.fn', st.dim, cfg['linear_attn_heads'], cfg['linear_attn_dim_head'])
                 sp += _feed_forward(pre + '.1.fn', st.dim)
+            elif st.kind == 'gateloop_time':
+                # ToTimeSequence(Residual(SimpleGateLoopLayer(dim))) (reference :1216-1222); third-party parameter names as reconstructed in
+                # oracle/thirdparty.py (unverified): RMSNorm gamma + Linear(dim, 3 dim, bias=False)
+                sp += [ParamSpec(pre + '.fn.fn.norm.gamma', (st.dim,), ('ones',))]
+                sp += _conv(pre + '.fn.fn.to_qkva.0', (st.dim * 3, st.dim), bias=False)
             elif st.kind == 'attend_time':
                 sp += _attention(pre + '.0.fn.fn', st.dim, cfg['attn_heads'], cfg['attn_dim_head'])
                 sp += _feed_forward(pre + '.1.fn.fn', st.dim)

@@ -11,7 +11,7 @@ generator's hinge loss through the image discriminator (forward values, computed
 constant 1 the reference uses without a VGG); ``forward(return_discr_loss=True, apply_gradient_penalty=False)`` the
 discriminator's hinge loss incl. caller-supplied multiscale discriminators.  ``video_contains_first_frame=False`` (headless
 clips) is supported on every method.  Backward, the gradient penalty, the gradient-norm adaptive weight (training mode with a
-VGG) and gateloop layers are out of scope here and raise ``NotImplementedError``.
+VGG) are out of scope here and raise ``NotImplementedError``.
 
 Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode) or
 torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode).  Default: bf16 when called
@@ -219,7 +219,7 @@ class VideoTokenizer(nn.Module):
             for dim in {st.dim, st.dim_out}:
                 if dim % 8 != 0:
                     raise NotImplementedError(f'layer width {dim} ({st.kind}): widths must be multiples of 8 (16-byte bf16 chunks)')
-            if st.kind in ('attend_space', 'attend_time', 'linear_attend_space') and not pow2(st.dim):
+            if st.kind in ('attend_space', 'attend_time', 'linear_attend_space', 'gateloop_time') and not pow2(st.dim):
                 raise NotImplementedError(f'{st.kind} at width {st.dim}: the RMSNorm / TokenShift kernels need a power-of-two width')
 
     # ------------------------------------------------------------------ weights

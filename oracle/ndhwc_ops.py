@@ -361,6 +361,23 @@ class CpuOps:
         step.what = 'copy_frames'
         return step
 
+    def gateloop_scan(self, dt, qkva, residual, out, B, T, Pn, Cc):
+        """mv2_gateloop_scan: h_t = sigmoid(a_t) h_{t-1} + kv_t, out_t = q_t h_t + residual_t along time, per pixel and channel"""
+        def step(stream):
+            n = B * T * Pn
+            z = qkva.reshape(-1)[: n * 3 * Cc].reshape(B, T, Pn, 3, Cc).to(self.acc)
+            r = residual.reshape(-1)[: n * Cc].reshape(B, T, Pn, Cc).to(self.acc)
+            q, kv, a = z[..., 0, :], z[..., 1, :], torch.sigmoid(z[..., 2, :])
+            h = torch.zeros(B, Pn, Cc, dtype=self.acc)
+            o = torch.empty_like(r)
+            for t in range(T):
+                h = a[:, t] * h + kv[:, t]
+                o[:, t] = q[:, t] * h + r[:, t]
+            out.reshape(-1)[: n * Cc].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [out]
+        step.what = 'gateloop_scan'
+        return step
+
     def pad_ndhwc(self, x, out, B, T, H, W, row_bytes, pt, ph, pw, mode, tail_bytes):
         """mv2_pad_ndhwc: F.pad(x, (pw, pw, ph, ph, pt, 0), mode) on an NDHWC tensor (mode 1 reflect / 2 replicate / 3 circular) + zero tail"""
         def step(stream):

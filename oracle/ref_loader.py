@@ -70,11 +70,7 @@ def install_shims():
     kf = _stub('kornia.filters', filter3d=_not_on_path)
     _stub('kornia', filters=kf)
 
-    class _SimpleGateLoopLayer:   # only for 'gateloop_time' (out of scope)
-        def __init__(self, *a, **k):
-            _not_on_path()
-
-    _stub('gateloop_transformer', SimpleGateLoopLayer=_SimpleGateLoopLayer)
+    _stub('gateloop_transformer', SimpleGateLoopLayer=thirdparty.SimpleGateLoopLayer)      # reconstruction, parity unpinned (oracle/thirdparty.py)
     _stub('vector_quantize_pytorch', LFQ=thirdparty.LFQ, FSQ=thirdparty.FSQ)
     _stub('taylor_series_linear_attention', TaylorSeriesLinearAttn=thirdparty.TaylorSeriesLinearAttn)
 

@@ -40,7 +40,7 @@ def parse_layers(layers, init_dim, max_dim):
         elif kind in ('compress_space', 'compress_time'):
             dim_out = params[0] if len(params) > 0 and params[0] is not None else dim * 2
             dim_out = min(dim_out, max_dim)
-        elif kind in ('attend_space', 'linear_attend_space', 'attend_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time'):
+        elif kind in ('attend_space', 'linear_attend_space', 'attend_time', 'gateloop_time', 'cond_residual', 'cond_attend_space', 'cond_attend_time'):
             pass
         else:
             raise ValueError(f'unknown / unscoped layer type {kind}')
@@ -236,6 +236,24 @@ def feed_forward(x, p, pre, cond=None):
     return F.conv3d(h, p[pre + 'net.2.weight'], p[pre + 'net.2.bias'])
 
 
+def gateloop_time(x, p, pre):
+    """'gateloop_time' (M:1216-1222): ToTimeSequence(Residual(SimpleGateLoopLayer(dim))) — per pixel a sequence over the frames.
+    Third-party layer restated from oracle/thirdparty.py (reconstruction, parity unpinned): RMSNorm (gamma * sqrt(dim)) -> Linear(dim, 3 dim)
+    = [q | kv | a] -> h_t = sigmoid(a_t) h_{t-1} + kv_t, out_t = q_t h_t; + x."""
+    B, C, T, H, W = x.shape
+    tok = x.permute(0, 3, 4, 2, 1).reshape(B * H * W, T, C)
+    n = rmsnorm_last(tok, p[pre + 'norm.gamma'])
+    q, kv, a = (n @ p[pre + 'to_qkva.0.weight'].t()).chunk(3, dim=-1)
+    a = a.sigmoid()
+    h = torch.zeros_like(kv[:, 0])
+    out = []
+    for t in range(T):
+        h = a[:, t] * h + kv[:, t]
+        out.append(q[:, t] * h)
+    o = torch.stack(out, dim=1) + tok
+    return o.reshape(B, H, W, T, C).permute(0, 4, 3, 1, 2)
+
+
 def token_shift(x):
     """M:250-253: second half of the channels delayed by one frame, zero at t = 0."""
     a, s = x.chunk(2, dim=1)
@@ -424,6 +442,8 @@ class OracleTokenizer:
         if kind == 'attend_time':
             x = time_attention(token_shift(x), p, pre + '.0.fn.fn.', self.attn_heads) + x
             return feed_forward(token_shift(x), p, pre + '.1.fn.fn.') + x
+        if kind == 'gateloop_time':
+            return gateloop_time(x, p, pre + '.fn.fn.')
         raise ValueError(kind)
 
     def encode(self, video, cond=None, video_contains_first_frame=True):

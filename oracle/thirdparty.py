@@ -350,3 +350,41 @@ class TaylorSeriesLinearAttn(nn.Module):
         out = torch.einsum('bhnd,bhde,bhn->bhne', q, kvs, qk_inv)
         out = out.transpose(1, 2).reshape(b, n, h * d)
         return self.to_out(out)
+
+
+# ----------------------------------------------------------------------------- gateloop-transformer (>= 0.2.2): SimpleGateLoopLayer
+class _GateLoopRMSNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return F.normalize(x, dim=-1) * self.scale * self.gamma
+
+
+class SimpleGateLoopLayer(nn.Module):
+    """RECONSTRUCTION from memory of gateloop_transformer.SimpleGateLoopLayer (package absent from /root/reference, pinned only as
+    `gateloop-transformer>=0.2.2` in setup.py:28): **parity unpinned**, parameter names `norm.gamma`, `to_qkva.0.weight` unverified.
+    prenorm RMSNorm -> Linear(dim, 3 dim, bias=False) split as [q | kv | a] -> per feature along the sequence
+    h_t = sigmoid(a_t) h_{t-1} + kv_t (an associative scan upstream), out_t = q_t h_t.  The reference call site
+    (magvit2_pytorch.py:1216-1222) constructs it with `dim` only and wraps it in Residual + ToTimeSequence."""
+
+    def __init__(self, dim, prenorm=True, use_heinsen=False, use_jax_associative_scan=False, post_ln=False, reverse=False):
+        super().__init__()
+        assert not post_ln and not reverse
+        self.dim = dim
+        self.norm = _GateLoopRMSNorm(dim) if prenorm else nn.Identity()
+        self.to_qkva = nn.Sequential(nn.Linear(dim, dim * 3, bias=False))
+
+    def forward(self, x, cache=None, return_cache=False):
+        assert cache is None and not return_cache
+        x = self.norm(x)
+        q, kv, a = self.to_qkva(x).chunk(3, dim=-1)          # 'b n (qkva d)': q first, then kv, then a
+        a = a.sigmoid()
+        h = torch.zeros_like(kv[:, 0])
+        out = []
+        for t in range(x.shape[1]):
+            h = a[:, t] * h + kv[:, t]
+            out.append(q[:, t] * h)
+        return torch.stack(out, dim=1)

@@ -138,3 +138,13 @@ def test_tokenize_stream_on_gpu(depth):
     want = [tok.tokenize(v.cuda()).cpu() for v in clips]
     got = list(tokenize_stream(tok, clips, depth=depth))
     assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gateloop_time_lockstep(dtype):
+    """mv2_gateloop_scan (written without GPU access) against the emulation, at a width where the qkva GEMM takes the MFMA path"""
+    kw = dict(image_size=32, init_dim=64, max_dim=128, codebook_size=256,
+              layers=('residual', 'compress_space', 'gateloop_time', 'compress_time', 'gateloop_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=67, randomize_se=True)
+    run_lockstep(cfg, sd, torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(68)), dtype)

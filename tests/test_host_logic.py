@@ -148,7 +148,7 @@ def test_ctor_and_call_asserts():
     with pytest.raises(ValueError):
         VideoTokenizer(image_size=32, layers=('residual', 'bogus'), codebook_size=64)  # reference :1312
     with pytest.raises(NotImplementedError):
-        VideoTokenizer(image_size=32, layers=('residual', 'gateloop_time'), codebook_size=64)
+        VideoTokenizer(image_size=32, layers=('residual', 'cond_linear_attend_space'), codebook_size=64, dim_cond=8)     # the reference cannot construct it either
     g = Golden('small_lfq')
     tok = emulated_tokenizer(g.kw, g.weights(), torch.float32)
     with pytest.raises(AssertionError):
@@ -924,3 +924,26 @@ def test_tokenize_stream_matches_plain_loop():
     got = list(tokenize_stream(tok, clips, depth=2))
     assert len(got) == 4 and all(torch.equal(a, tok.tokenize(v)) for a, v in zip(got, clips))
     assert list(tokenize_stream(tok, [], depth=3)) == []
+
+
+@pytest.mark.parametrize('vcff,frames', [(True, 9), (False, 8)])
+def test_gateloop_time_matches_oracle(vcff, frames):
+    """'gateloop_time' (reference :1216-1222; the third-party SimpleGateLoopLayer is a reconstruction, parity unpinned): RMSNorm folded
+    into one pointwise GEMM [q | kv | a], then mv2_gateloop_scan along time with the residual add."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64,
+              layers=('residual', 'compress_space', 'gateloop_time', 'compress_time', 'gateloop_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=12, randomize_se=True)
+    assert 'encoder_layers.2.fn.fn.to_qkva.0.weight' in sd and sd['decoder_layers.1.fn.fn.norm.gamma'].shape == (32,)
+    orc = OracleTokenizer(sd, **cfg)
+    v = torch.randn(2, 3, frames, 16, 16, generator=torch.Generator().manual_seed(13))
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    codes, recon = tok(v, return_codes=True, return_recon=True, video_contains_first_frame=vcff)
+    assert torch.equal(codes, ocodes) and (recon - orecon).abs().max().item() <= 5e-6
+    assert tok._plan(2, frames, headless=not vcff)[0].step_names.count('gateloop_scan') == 4
+    # causal along time: a later frame cannot change earlier latent frames
+    a = tok.encode(v, video_contains_first_frame=vcff)
+    v2 = v.clone(); v2[:, :, 5:] += 1.0
+    b = tok.encode(v2, video_contains_first_frame=vcff)
+    assert torch.equal(a[:, :, :2], b[:, :, :2]) and not torch.equal(a, b)

@@ -407,3 +407,21 @@ def test_lfq_spherical_matches_reference(ncb):
     # normalisation keeps every sign: the ids are those of the plain quantizer, the reconstruction is not
     pcodes, precon = OracleTokenizer(sd, **dict(cfg, lfq_spherical=False))(v, return_codes=True, return_recon=True)
     assert torch.equal(pcodes, ocodes) and (precon - orecon).abs().max().item() > 1e-2
+
+
+def test_gateloop_time_matches_reference():
+    """'gateloop_time' through the reference's own control flow (ToTimeSequence(Residual(SimpleGateLoopLayer)), M:1216-1222) with the
+    third-party layer replaced by its reconstruction (oracle/thirdparty.py, parity unpinned): key set, ids, reconstruction."""
+    kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64,
+              layers=('residual', 'compress_space', 'gateloop_time', 'compress_time', 'gateloop_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=12, randomize_se=True)
+    ref = make_reference_tokenizer(**kw)
+    rsd = {k: v for k, v in ref.state_dict().items() if not k.startswith('discr.')}
+    assert set(rsd) == set(sd) and all(tuple(rsd[k].shape) == tuple(sd[k].shape) for k in sd)
+    ref.load_state_dict(sd, strict=False)
+    v = torch.randn(2, 3, 9, 16, 16, generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        codes, recon = ref(v, return_codes=True, return_recon=True)
+    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
+    assert torch.equal(ocodes, codes) and torch.allclose(orecon, recon, atol=1e-5, rtol=0)
