@@ -75,3 +75,33 @@ def test_taylor_attention_matches_upstream():
     x = torch.randn(3, 40, 64)
     with torch.no_grad():
         assert torch.allclose(up(x), mine(x), atol=1e-5)
+
+
+def test_lfq_spherical_matches_upstream():
+    vq = _real('vector_quantize_pytorch')
+    torch.manual_seed(0)
+    kw = dict(dim=32, codebook_size=256, num_codebooks=2, entropy_loss_weight=0.1, commitment_loss_weight=1., diversity_gamma=2.5,
+              soft_clamp_input_value=10., spherical=True)
+    up, mine = vq.LFQ(**kw), TP.LFQ(**kw)
+    mine.load_state_dict(up.state_dict(), strict=False)
+    x = torch.randn(2, 32, 3, 4, 4)
+    for train in (False, True):
+        up.train(train); mine.train(train)
+        with torch.no_grad():
+            (q0, i0, a0), _ = up(x, return_loss_breakdown=True)
+            (q1, i1, a1), _ = mine(x, return_loss_breakdown=True)
+        assert torch.equal(i0, i1) and torch.allclose(q0, q1, atol=1e-6)
+        assert torch.allclose(torch.as_tensor(a0).float(), torch.as_tensor(a1).float(), atol=1e-5)
+    assert torch.allclose(up.indices_to_codes(i0), mine.indices_to_codes(i0), atol=1e-6)
+
+
+def test_simple_gateloop_layer_matches_upstream():
+    gl = _real('gateloop_transformer')
+    print('gateloop-transformer', _version('gateloop-transformer'))
+    torch.manual_seed(0)
+    up, mine = gl.SimpleGateLoopLayer(dim=32, use_heinsen=False), TP.SimpleGateLoopLayer(dim=32)
+    assert set(up.state_dict()) == set(mine.state_dict()), (set(up.state_dict()), set(mine.state_dict()))      # the parameter names the weight contract relies on
+    mine.load_state_dict(up.state_dict())
+    x = torch.randn(3, 9, 32)
+    with torch.no_grad():
+        assert torch.allclose(up(x), mine(x), atol=1e-5)
