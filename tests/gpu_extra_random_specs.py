@@ -92,52 +92,6 @@ def test_pad_mode_lockstep_and_fixture(pad_mode, dtype):
             assert (recon.cpu() - torch.from_numpy(np.asarray(f.z['recon']))).abs().max().item() <= 5e-4
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('channels', [1, 5, 8])
-def test_input_channel_counts_lockstep(channels, dtype):
-    """8-channel input pixels (5 .. 8 channels): the round-1 conv_in layout, not exercised by the default suite of round 2"""
-    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, channels=channels, layers=('residual', 'compress_space', 'compress_time', 'residual'))
-    cfg = make_cfg(**kw)
-    sd = init_state_dict(cfg, seed=63, randomize_se=True)
-    run_lockstep(cfg, sd, torch.randn(2, channels, 5, 32, 32, generator=torch.Generator().manual_seed(64)), dtype)
-
-
-def test_lfq_spherical_fp32_vs_oracle():
-    """eval-mode lfq_spherical: the LFQ kernels with scale = 1/sqrt(code dims) (a value of `scale` the default suite never passes)"""
-    kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, lfq_spherical=True, layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time'))
-    cfg = make_cfg(**kw)
-    sd = init_state_dict(cfg, seed=65, randomize_se=True)
-    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(66))
-    run_lockstep(cfg, sd, v, torch.float32)
-    run_lockstep(cfg, sd, v, torch.bfloat16)
-    ocodes, orecon = OracleTokenizer(sd, **cfg)(v, return_codes=True, return_recon=True)
-    tok = hip_tokenizer(dict(kw, use_gan=False), sd, torch.float32)
-    codes, recon = tok(v.cuda(), return_codes=True, return_recon=True)
-    assert (codes.cpu() != ocodes).float().mean().item() <= 0.005
-    if torch.equal(codes.cpu(), ocodes):
-        assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
-    assert (tok.decode_from_code_indices(ocodes.cuda()).cpu() - orecon).abs().max().item() <= 5e-4
-    tok2 = VideoTokenizer(**kw, use_gan=False, perceptual_loss_weight=0., seed=0)
-    tok2.load_state_dict(sd)
-    tok2 = tok2.cuda()
-    tok2.compute_dtype = torch.float32
-    tok2.train()
-    total, br = tok2(v.cuda(), return_loss=True)
-    want, d = OracleTokenizer(sd, **cfg).forward_loss(v, training=True)
-    assert abs(float(total) - float(want)) <= 3e-4 * max(1., abs(float(want))) and abs(float(br.lfq_aux_loss) - float(d['aux'])) <= 3e-4
-
-
-@pytest.mark.parametrize('depth', [1, 2, 3])
-def test_tokenize_stream_on_gpu(depth):
-    """uploads and id downloads on a side stream, compute on the current stream: same ids, in order, as clip-by-clip tokenize()"""
-    from magvit2_pytorch_amd.streaming import tokenize_stream
-    from tests._util import Golden
-    g = Golden('small_lfq')
-    tok = hip_tokenizer(g.kw, g.weights(), torch.bfloat16)
-    clips = [torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(80 + i)).pin_memory() for i in range(7)]
-    want = [tok.tokenize(v.cuda()).cpu() for v in clips]
-    got = list(tokenize_stream(tok, clips, depth=depth))
-    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
