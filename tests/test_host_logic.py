@@ -291,7 +291,7 @@ def test_plan_cache_is_bounded():
     for b in (1, 2, 3, 1):
         tok.tokenize(torch.randn(b, 3, 5, 32, 32, generator=torch.Generator().manual_seed(b)))
         assert len(tok._plans) <= 2
-    assert {k[2] for k in tok._plans} == {3, 1}            # least recently used (B = 2) was dropped
+    assert {p.B for p in tok._plans.values()} == {3, 1}            # least recently used (B = 2) was dropped
 
 
 # ------------------------------------------------------------------------------- forward(return_loss=True): host logic on the CPU emulation

@@ -122,7 +122,7 @@ def test_training_mode_forward_value_is_the_straight_through_form():
     tok, _ = _pair(LOSS_KW, 23, torch.float32, True)
     v = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(24)).cuda()
     tok(v, return_loss=True)
-    plan_t = [p for k, p in tok._plans.items() if k[-1]][0]
+    plan_t = [p for p in tok._plans.values() if p.train][0]
     recon_t, ids_t = plan_t.recon.clone(), plan_t.ids.clone()
     tok.eval()
     codes, recon_e = tok(v, return_codes=True, return_recon=True)
