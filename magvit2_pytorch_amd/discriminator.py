@@ -11,7 +11,8 @@ Lowering (all through ``mv2_conv`` unless noted), per block at resolution H x W:
          2x2 stride-2 convolution (weight[o][c*4 + p1*2 + p2] -> tap (p1, p2) of channel c); 1/sqrt 2 is folded into the
          weights and biases of both summands, and through the positively homogeneous leaky_relu in the last block
   x    = x + LinearSpaceAttention(x); x = x + FeedForward(x)          M:632-645 (Taylor attention kernels, GEGLU epilogue)
-to_logits: conv3x3 + leaky_relu, then Linear(C*4*4 -> 1) as a 4x4 'valid' convolution storing fp32 (M:660-666).
+to_logits: conv3x3 + leaky_relu, then Linear(C*F*F -> 1) as an F x F 'valid' convolution storing fp32 (M:654-666); F = image_size //
+2 ** num_layers is 4 for power-of-two sizes and 4..7 otherwise (e.g. 96 -> 6).
 ``antialiased_downsample=True`` needs kornia's filter3d (absent here and in the reference's default): raises.
 """
 from __future__ import annotations
@@ -33,6 +34,11 @@ def discriminator_dims(dim, image_size, channels=3, max_dim=512):
     return list(zip(dims[:-1], dims[1:]))
 
 
+def discriminator_last_fmap(image_size):
+    """side of the feature map to_logits flattens: image_size // 2 ** num_layers (reference :654-657); 4 for power-of-two sizes, 4..7 otherwise"""
+    return image_size // (2 ** int(math.log2(image_size) - 2))
+
+
 def discriminator_param_specs(dim, image_size, channels=3, max_dim=512, linear_attn_heads=16, linear_attn_dim_head=8) -> List[S.ParamSpec]:
     sp: List[S.ParamSpec] = []
     pairs = discriminator_dims(dim, image_size, channels, max_dim)
@@ -51,7 +57,7 @@ def discriminator_param_specs(dim, image_size, channels=3, max_dim=512, linear_a
         sp += S._conv(a + '.1.fn.net.2', (cout, inner, 1, 1))
     last = pairs[-1][1]
     sp += S._conv('to_logits.0', (last, last, 3, 3))
-    sp += S._conv('to_logits.3', (1, last * 16))
+    sp += S._conv('to_logits.3', (1, last * discriminator_last_fmap(image_size) ** 2))
     return sp
 
 
@@ -105,7 +111,8 @@ class _DiscrPacked:
             put(pre + '.ff2', P.pack_pointwise(f(pre + '.net.2.weight').flatten(1), f(pre + '.net.2.bias'), dtype, k_pad=hpad))
         cl = self.pairs[-1][1]
         put('to_logits.0', P.pack_conv3d(f('to_logits.0.weight')[:, :, None], f('to_logits.0.bias'), dtype))
-        put('to_logits.3', P.pack_conv3d(f('to_logits.3.weight').reshape(1, cl, 4, 4)[:, :, None], f('to_logits.3.bias'), dtype))
+        fm = discriminator_last_fmap(hp['image_size'])         # Rearrange('b ... -> b (...)') flattens (c, h, w): Linear == fm x fm 'valid' conv
+        put('to_logits.3', P.pack_conv3d(f('to_logits.3.weight').reshape(1, cl, fm, fm)[:, :, None], f('to_logits.3.bias'), dtype))
 
 
 class _DiscrPlan(Plan):
@@ -159,7 +166,8 @@ class _DiscrPlan(Plan):
             H, W = Ho, Wo
         h = self._conv(steps, 'to_logits.0', pm.convs['to_logits.0'], x, ph=1, pw=1, act=P.ACT_LRELU)
         self.arena.put(x.t)
-        assert (h.H, h.W) == (4, 4), 'to_logits expects the 4 x 4 feature map the reference ends on'
+        fm = discriminator_last_fmap(pm.hp['image_size'])
+        assert (h.H, h.W) == (fm, fm), 'to_logits flattens the feature map the last block leaves'
         self._conv(steps, 'to_logits.3', pm.convs['to_logits.3'], h, Ho=1, Wo=1, check_bounds=False, store=P.STORE_NCTHW_F32,
                    out_t=self.logits, out_c=4)
         self.arena.put(h.t)
@@ -173,7 +181,12 @@ class Discriminator(nn.Module):
             raise NotImplementedError('antialiased_downsample needs kornia.filters.filter3d (absent); the reference default is False')
         assert ff_mult == 4 and channels <= 4
         image_size = image_size if isinstance(image_size, int) else min(image_size)
-        assert image_size >= 8 and image_size & (image_size - 1) == 0, 'power-of-two image sizes'
+        assert image_size >= 8, 'the reference builds int(log2(image_size) - 2) >= 1 blocks'
+        nl = int(math.log2(image_size) - 2)
+        # every block but the last halves the map through 'b c (h p1) (w p2) -> b (c p1 p2) h w' (reference :568): sizes that are not a
+        # multiple of 2 ** num_layers construct in the reference too and fail in its forward; the same is deferred to forward() here
+        self._geometry_error = None if image_size % (2 ** nl) == 0 else (
+            f'image_size {image_size} is not a multiple of 2 ** {nl}: the reference discriminator cannot halve an odd feature map either')
         self.hp = dict(dim=dim, image_size=image_size, channels=channels, max_dim=max_dim, linear_attn_heads=linear_attn_heads,
                        linear_attn_dim_head=linear_attn_dim_head)
         gen = torch.Generator().manual_seed(seed if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
@@ -230,6 +243,8 @@ class Discriminator(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         """images (B, C, H, W) -> logits (B,) fp32 (reference Discriminator.forward M:670-676)."""
+        if self._geometry_error:
+            raise ValueError(self._geometry_error)
         assert x.ndim == 4 and x.shape[1] == self.hp['channels'] and x.shape[-2:] == (self.hp['image_size'],) * 2
         ops, dt = self._backend(), self._dtype()
         kpm = (dt, self._weights_version)

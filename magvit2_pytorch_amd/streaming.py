@@ -57,6 +57,8 @@ def tokenize_stream(tokenizer, clips: Iterable[torch.Tensor], depth: int = 2, co
         main.wait_event(ev)                                       # the clip has landed
         ids = tokenizer.tokenize(dv, cond=dc)                     # D2D into the plan's input buffer + graph replay, on `main`
         dv.record_stream(main)
+        if dc is not None:
+            dc.record_stream(main)                                # consumed on `main` by the copy into plan.cond_in
         computed = torch.cuda.Event()
         computed.record(main)
         with torch.cuda.stream(side):

@@ -139,6 +139,11 @@ class VideoTokenizer(nn.Module):
             lfq_spherical=bool(lfq_spherical) and not use_fsq)
         self.has_cond = S.has_cond(self.cfg)
         self.dim_cond = dim_cond
+        if _exists(dim_cond) and any((l if isinstance(l, str) else l[0]) == 'attend_time' for l in layers):
+            # the reference builds the 'attend_time' FeedForward with dim_cond (M:1307, 1312: AdaptiveRMSNorm keys norm.to_gamma.*) but
+            # never passes cond to it, so its own forward raises; refuse at construction instead of carrying a wrong key set
+            raise ValueError("'attend_time' with dim_cond set: the reference builds that layer's FeedForward conditioned (M:1307) and then "
+                             "fails in forward (no cond is passed); use 'cond_attend_time' in a conditioned tokenizer")
         if self.has_cond:
             assert _exists(dim_cond), 'dim_cond must be passed into VideoTokenizer, if tokenizer is to be conditioned'   # reference :1151
             kinds = [ld[0] if isinstance(ld, tuple) else ld for ld in layers]
@@ -402,6 +407,16 @@ class VideoTokenizer(nn.Module):
                 g = graph
             g.replay()
 
+    @staticmethod
+    def _launch(plan: Plan, steps):
+        """eager launches outside the captured sequences (loss tails, hinge loss): on the backend's device, whatever is current"""
+        ops = plan.ops
+        if getattr(ops, 'name', '') != 'hip':
+            plan.run(steps)
+            return
+        with torch.cuda.device(ops.device):
+            plan.run(steps)
+
     # ------------------------------------------------------------------ helpers
     def _check_video(self, video_or_images, video_contains_first_frame=True):
         """-> (5-D video, video_contains_first_frame); an image is a one-frame clip that contains its first frame (reference :1681-1685)"""
@@ -540,7 +555,7 @@ class VideoTokenizer(nn.Module):
                 codes = self._ids_out(plan)
                 return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
             if return_recon_loss_only:
-                plan.run(plan.loss_steps[:plan.n_recon_steps])
+                self._launch(plan, plan.loss_steps[:plan.n_recon_steps])
                 return self._recon_loss(plan), recon
             return recon
 
@@ -573,7 +588,7 @@ class VideoTokenizer(nn.Module):
         def hinge(fake, real):
             out = plan.ops.empty((1,), torch.float32)
             fake, real = fake.reshape(-1).float().contiguous(), real.reshape(-1).float().contiguous()
-            plan.run([plan.ops.hinge_discr_loss(fake, real, fake.numel(), out)])
+            self._launch(plan, [plan.ops.hinge_discr_loss(fake, real, fake.numel(), out)])
             return out[0].clone()
 
         discr_loss = hinge(fake_logits, real_logits)
@@ -614,7 +629,7 @@ class VideoTokenizer(nn.Module):
             pm = plan.pm
             z = plan.prequant[: plan.n_tokens].reshape(plan.n_tokens, pm.ncb, pm.cb_dim)
             z.copy_(torch.nn.functional.normalize(z, dim=-1))
-            plan.run(plan.loss_steps[nr:])
+            self._launch(plan, plan.loss_steps[nr:])
         else:
             self._run(plan, key, 'fwd+loss', [plan.enc_steps, plan.q_steps, plan.dec_steps, plan.loss_steps])
         recon_loss = self._recon_loss(plan)
@@ -626,12 +641,13 @@ class VideoTokenizer(nn.Module):
                 dist.all_reduce(plan.lfq_sums)
                 dist.all_reduce(cnt)
                 n_tokens = float(cnt.item())
-            plan.run([plan.ops.lfq_losses(plan.lfq_sums, n_tokens, plan.pm.cb_dim, plan.pm.ncb, self.lfq_diversity_gamma,
+            self._launch(plan, [plan.ops.lfq_losses(plan.lfq_sums, n_tokens, plan.pm.cb_dim, plan.pm.ncb, self.lfq_diversity_gamma,
                                           self.lfq_entropy_loss_weight, self.lfq_commitment_loss_weight, plan.lfq_losses)])
             ls = plan.lfq_losses.clone()
             aux, breakdown = ls[3], QuantizerLossBreakdown(ls[0], ls[1], ls[2])
         else:
-            aux, breakdown = zero, QuantizerLossBreakdown(zero, zero, zero)       # eval mode / FSQ: aux loss is zero (M:1705-1709)
+            # eval-mode LFQ: every term is zero; FSQ: the reference's breakdown is None (M:1700-1703)
+            aux, breakdown = zero, (None if self.use_fsq else QuantizerLossBreakdown(zero, zero, zero))
         total = recon_loss + aux * self.quantizer_aux_loss_weight
         perceptual, gen_loss, adaptive_weight, ms_losses, ms_weights = zero, zero, 0., [], []
         if not (self.use_vgg or self.has_gan or self.has_multiscale_discrs):

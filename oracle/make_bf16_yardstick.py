@@ -1,0 +1,65 @@
+"""
+TEST INFRASTRUCTURE — not product code.  Authoring container only (needs /root/reference).
+
+The "stated fp tolerance" of the bf16 GPU path is the reference's OWN bf16 drift: the reference VideoTokenizer run under
+``torch.autocast('cpu', dtype=torch.bfloat16)`` against the same module in fp32, same weights, same clip.  One clip gives one
+sample of a chaotic quantity (a 1-ulp change upstream moves which tokens flip), so the yardstick is taken over several data
+seeds and the GPU test compares MEANS over the same seeds (tests/test_parity_gpu.py::test_bf16_drift_within_reference_yardstick).
+
+    python oracle/make_bf16_yardstick.py            # writes tests/golden/bf16_yardstick.json
+
+Per case and data seed: ids mismatch (fraction of tokens), recon mean|d| and max|d| of autocast-bf16 vs fp32, both from the
+reference executed in place (oracle/ref_loader.py).
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from magvit2_pytorch_amd.spec import README_LAYERS, init_state_dict, make_cfg   # noqa: E402
+from oracle.ref_loader import make_reference_tokenizer                          # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'bf16_yardstick.json')
+
+# name: (ctor kwargs, clip shape, weight seed, data seeds) — weights / first data seed are those of the golden fixtures and of bench.py
+CASES = {
+    'mid_lfq': (dict(image_size=64, init_dim=16, max_dim=128, codebook_size=1024, layers=README_LAYERS), (1, 3, 9, 64, 64), 5, [6, 101, 102, 103, 104, 105]),
+    'cfg2_video128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (1, 3, 17, 128, 128), 0,
+                         [1, 101, 102, 103, 104, 105]),
+}
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    res = dict(torch_version=torch.__version__, note='reference VideoTokenizer, CPU: autocast(bfloat16) vs fp32; see oracle/make_bf16_yardstick.py', cases={})
+    for name, (kw, shape, wseed, dseeds) in CASES.items():
+        cfg = make_cfg(**kw)
+        sd = init_state_dict(cfg, seed=wseed, randomize_se=True)
+        ref = make_reference_tokenizer(**kw)
+        ref.load_state_dict(sd, strict=False)
+        rows = []
+        for ds in dseeds:
+            v = torch.randn(*shape, generator=torch.Generator().manual_seed(ds))
+            t0 = time.time()
+            with torch.no_grad():
+                c32, r32 = ref(v, return_codes=True, return_recon=True)
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    c16, r16 = ref(v, return_codes=True, return_recon=True)
+            d = (r16.float() - r32).abs()
+            rows.append(dict(data_seed=ds, ids_mismatch=float((c16 != c32).float().mean()), recon_mean_abs=float(d.mean()), recon_max_abs=float(d.max())))
+            print(name, rows[-1], f'{time.time() - t0:.1f}s', flush=True)
+        n = len(rows)
+        res['cases'][name] = dict(kw={k: (list(x) if isinstance(x, tuple) else x) for k, x in kw.items()}, shape=list(shape), weight_seed=wseed, rows=rows,
+                                  mean_ids_mismatch=sum(r['ids_mismatch'] for r in rows) / n, mean_recon_mean_abs=sum(r['recon_mean_abs'] for r in rows) / n)
+        with open(OUT, 'w') as f:
+            json.dump(res, f, indent=1)
+    print('wrote', OUT)
+
+
+if __name__ == '__main__':
+    main()

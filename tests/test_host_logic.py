@@ -461,6 +461,27 @@ def test_discriminator_lowering_matches_oracle():
         Discriminator(**kw, antialiased_downsample=True)
 
 
+def test_discriminator_non_power_of_two_size_and_default_tokenizer_ctor():
+    """ADVICE r2: the reference discriminator takes any size (num_layers = int(log2 n - 2), to_logits flattens an n // 2**L map, M:607,
+    654-657): 24 -> 2 blocks ending on 6 x 6.  A default-constructed tokenizer (use_gan=True) at image_size 96 must construct."""
+    from magvit2_pytorch_amd.discriminator import Discriminator
+    from oracle.restate import discriminator_forward
+    kw = dict(dim=8, image_size=24, channels=3, max_dim=64)
+    d = Discriminator(**kw, seed=4)
+    assert d.state_dict()['to_logits.3.weight'].shape == (1, 64 * 36)
+    d._set_backend(CpuOps())
+    d.compute_dtype = torch.float32
+    x = torch.randn(2, 3, 24, 24, generator=torch.Generator().manual_seed(5))
+    want = discriminator_forward(x, {'discr.' + k: v for k, v in d.state_dict().items()}, 'discr.', **kw)
+    assert (d(x) - want).abs().max().item() <= 2e-6
+    tok = VideoTokenizer(image_size=96, init_dim=8, max_dim=32, codebook_size=64, layers=('residual', 'compress_space'), seed=0)
+    assert tok.discr is not None and tok.state_dict()['discr.to_logits.3.weight'].shape[1] % 36 == 0
+    bad = Discriminator(dim=8, image_size=22, channels=3, max_dim=64, seed=0)      # 22 -> 11 -> odd: the reference fails in forward too
+    bad._set_backend(CpuOps())
+    with pytest.raises(ValueError):
+        bad(torch.zeros(1, 3, 22, 22))
+
+
 def test_forward_return_discr_loss_matches_oracle():
     kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=64, layers=('residual', 'compress_space', 'compress_time', 'residual'))
     cfg = make_cfg(**kw)
