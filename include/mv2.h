@@ -296,6 +296,26 @@ int mv2_pw_se_rows(int dtype, int64_t rows, int P, int C);
 int mv2_pw_se(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk, void* out,
               float* se_part, int64_t rows, int P, int C, void* stream);
 
+/* The WHOLE tail of a ResidualUnit at C = 128 / 256 / 512, bf16, in ONE launch (rutail.hip): y = ELU(conv1x1x1(h) + b) (reference
+ * M:938-940), out = SqueezeExcite(y) + x (M:221-240 per frame, Residual M:944).  Replaces mv2_pw_se -> mv2_se_gate -> mv2_se_apply
+ * (and the rec_fc1 / fc2_apply form): the output tile never leaves LDS; workgroups of one frame meet through pooling records and an
+ * arrival counter inside the launch (tiles are handed out at workgroup start, so there is no residency requirement).
+ *   in / residual / out : rows x C bf16 (out may alias residual; must not alias in)
+ *   wp                  : the C x C 1x1x1 kernel, fragment-major (as mv2_pw_se)
+ *   se_w1t_bf16         : [C][hidden] bf16 = net[0].weight transposed; se_w2t_bf16: [hidden][C] bf16 = net[2].weight transposed
+ *                         (bf16: what the reference's own bf16 autocast does to these 1x1 convs); biases fp32; hidden must be C / 2
+ *   rec                 : workspace, mv2_ru_tail_rec_bytes(rows, P, C, mv2_ru_tail_rows(...)) bytes (records of C + 4 floats)
+ *   sync                : mv2_ru_tail_sync_bytes(rows / P) bytes, ZERO before the first launch; every launch leaves it zero
+ *                         (word 2 is an error flag: set when a bounded wait expired — results are then invalid)
+ * mv2_ru_tail_rows: rows per workgroup (32 or 64), 0 when the shape is not eligible (the caller keeps the multi-launch form). */
+int mv2_ru_tail_rows(int dtype, int64_t rows, int P, int C, int hidden);
+size_t mv2_ru_tail_rec_bytes(int64_t rows, int P, int C, int rows_per_workgroup);
+size_t mv2_ru_tail_sync_bytes(int frames);
+int mv2_ru_tail(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk,
+                const void* se_w1t_bf16, const float* se_b1, const void* se_w2t_bf16, const float* se_b2,
+                const void* residual, void* out, float* rec, size_t rec_bytes, void* sync, size_t sync_bytes,
+                int64_t rows, int P, int C, int hidden, void* stream);
+
 /* Training-mode LFQ (third-party LFQ.forward with self.training, reference call site M:1705, loss weights M:1067-1072, recon loss
  * M:1722).  mv2_lfq_train = mv2_lfq with the straight-through forward value z + (q - z) (prequant is mandatory: it feeds
  * the statistics).  mv2_lfq_stats: per codebook the token-SUMMED softmax probabilities over all K = 2^cb_dim codes

@@ -153,6 +153,16 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 #ifndef MV2_C3_OWNQ
 #define MV2_C3_OWNQ 0
 #endif
+// HTAB: the six halo row offsets of a thread are kept in a thread-private LDS table, written once per SEGMENT (tile), instead of being
+// re-derived per GROUP.  The per-group derivation is, per row, a division by 18 (v_mul_hi_i32), two 64-bit multiply-adds and an exec
+// branch: ~70 issue cycles per row = ~450 per group at the top of tap 0, where a single wave per SIMD has no MFMA in flight to hide
+// them (the ISA of the round-2 kernel; a group is 9 x 256 MFMA cycles).  With the table a row costs one saturating add: entries of rows
+// in the spatial zero padding hold 0xffffffff, which stays out of range under uadd.sat whatever the group's frame / chunk offset.
+// 1: table reads at the top of tap 0, the six loads between the two MFMA batches of tap 0.  2: loads spread over taps 0-2 (two rows
+// each), LDS writes over taps 5-7.  The table lives behind the two halo images inside the reduce region (free while taps run).
+#ifndef MV2_C3_HTAB
+#define MV2_C3_HTAB 0
+#endif
 #ifndef MV2_C3_PSETS
 #define MV2_C3_PSETS 3
 #endif
@@ -181,6 +191,8 @@ struct C3Lds {
     static constexpr int kW2 = kConst2 + (FUSED ? 512 : 0);           // fused stage: 64 x 64 pointwise weights, staged once per workgroup
     static constexpr int kFlag = kW2 + (FUSED ? BCO * 128 : 0);
     static constexpr int kLds = kFlag + 16;
+    static constexpr int kHtab = 2 * HALO_BYTES;                      // HTAB: [NH][256] row offsets behind the halo images (reduce region: dead during taps)
+    static_assert(!MV2_C3_HTAB || kHtab + NH * 256 * 4 <= kMain, "halo offset table fits behind the halo images");
     static_assert(kLds <= 80 * 1024, "two workgroups per CU");
 };
 
@@ -345,6 +357,40 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo, 0, 0);
         }
     };
+#if MV2_C3_HTAB
+    // thread-private table of the segment's halo row offsets (see MV2_C3_HTAB above); rewritten by next_seg() for every segment
+    auto write_htab = [&](const Seg& S) {
+        const int h0 = S.ti.thi * TH, w0 = S.ti.twi * TW;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));        // opaque: otherwise the lane-only parts are hoisted to kernel entry and spilled around the tap loop
+        const int r0_ = tid_o >> 3, c_ = tid_o & 7;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hr = r0_ + RPP * i;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const bool ok = hr < HR && (unsigned)(h0 - 1 + hy) < (unsigned)H && (unsigned)(w0 - 1 + hx) < (unsigned)W_;
+            // wrapping arithmetic: hw_base may be "negative" for edge tiles, the sum of a valid row is a true offset inside the frame
+            const uint32_t e = ok ? S.hw_base + (uint32_t)(hy * W_ + hx) * row_bytes + (uint32_t)c_ * 16u : 0xffffffffu;
+            *(uint32_t*)(smem + L::kHtab + (i * 256 + tid_o) * 4) = e;
+        }
+    };
+    uint32_t htv[NH];
+    auto read_htab = [&](auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));        // the table address is re-derived: nothing lane-derived is carried through the loop
+#pragma unroll
+        for (int i = LO; i < HI; ++i) htv[i] = *(const uint32_t*)(smem + L::kHtab + (i * 256 + tid_o) * 4);
+    };
+    auto issue_halo_tab = [&](const Seg& S, int chunk, int it, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const int t_in = S.ti.t + it - d.pt;
+        const uint32_t gbase = (uint32_t)(((int64_t)S.ti.b * T + t_in) * (int64_t)frame_bytes) + (uint32_t)chunk * 128u;      // uniform
+#pragma unroll
+        for (int i = LO; i < HI; ++i)
+            hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)__builtin_elementwise_add_sat(htv[i], gbase), 0, 0);
+    };
+#endif
     auto write_halo = [&](char* img, auto lo_c, auto hi_c) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #if MV2_C3_HPRO
@@ -358,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
 #else
 #pragma unroll
         for (int i = LO; i < HI; ++i)
-            if (r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hreg[i];
+            if ((MV2_C3_HTAB && (i + 1) * RPP <= HR) || r0 + RPP * i < HR) *(i32x4*)(img + lds_wr + i * RPP * ROWP) = hreg[i];     // only the last pass is partial
 #endif
     };
     auto issue_w1 = [&](const Seg& S, uint32_t so, int a, i32x4& dst) {
@@ -386,6 +432,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     auto issue_first = [&](const Seg& S) {     // halo of the segment's first group + the first RING weight fragments + its bias values
 #if MV2_C3_HPRO
         issue_halo_first(S, S.cur_chunk, S.cur_it);
+#elif MV2_C3_HTAB
+        read_htab(IC<0>{}, IC<NH>{});
+        issue_halo_tab(S, S.cur_chunk, S.cur_it, IC<0>{}, IC<NH>{});
 #else
         issue_halo(S, S.cur_chunk, S.cur_it, IC<0>{}, IC<NH>{});
 #endif
@@ -409,7 +458,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     auto next_seg = [&](uint32_t x, Seg& O) {
         while (x < x1) {
             O = make_seg(x);
+#if MV2_C3_HTAB
+            if (O.ge > O.gb) { write_htab(O); return true; }
+#else
             if (O.ge > O.gb) return true;
+#endif
             x = O.xe;
         }
         return false;
@@ -451,6 +504,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                 if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH / 2>{});
                 if constexpr (TP == 4) { write_halo(smem + other, IC<0>{}, IC<NH / 2>{}); issue_halo(S, S.nxt_chunk, S.nxt_it, IC<NH / 2>{}, IC<NH>{}); }
                 if constexpr (TP == 8) write_halo(smem + other, IC<NH / 2>{}, IC<NH>{});
+            } else if constexpr (MV2_C3_HTAB == 1) {
+#if MV2_C3_HTAB
+                if constexpr (TP == 0) read_htab(IC<0>{}, IC<NH>{});
+#endif
+            } else if constexpr (MV2_C3_HTAB == 2) {
+#if MV2_C3_HTAB
+                if constexpr (TP < 3) read_htab(IC<2 * TP>{}, IC<2 * TP + 2>{});
+#endif
             } else {
                 if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH>{});
             }
@@ -470,7 +531,16 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                 else asm volatile("" : "+v"(wring[SLOT]));       // keep the slot live and opaque
             };
             static_assert(WCO == 2, "two channel tiles per wave");
-            frag(IC<0>{}); frag(IC<1>{});
+            frag(IC<0>{});
+#if MV2_C3_HTAB
+            // the table values have had four MFMAs of flight; the loads go out under the second batch
+            if constexpr (MV2_C3_HTAB == 1 && !MV2_C3_HSPLIT && TP == 0) issue_halo_tab(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH>{});
+            if constexpr (MV2_C3_HTAB == 2 && !MV2_C3_HSPLIT && TP < 3) issue_halo_tab(S, S.nxt_chunk, S.nxt_it, IC<2 * TP>{}, IC<2 * TP + 2>{});
+#endif
+            frag(IC<1>{});
+            if constexpr (MV2_C3_HTAB == 2 && !MV2_C3_HSPLIT) {
+                if constexpr (TP >= HWT && TP < HWT + 3) write_halo(smem + other, IC<2 * (TP - HWT)>{}, IC<2 * (TP - HWT) + 2>{});
+            } else
             if constexpr (!MV2_C3_HSPLIT && TP == HWT) write_halo(smem + other, IC<0>{}, IC<NH>{});   // image of group gi-1: its last reader passed the previous barrier
             if constexpr (PSETS == 2 && TP == 8) {      // the next group's tap 0 reads set 0
 #pragma unroll

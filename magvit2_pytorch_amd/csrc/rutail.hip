@@ -1,0 +1,410 @@
+// mv2_ru_tail — the whole tail of a ResidualUnit in ONE launch (bf16, C = 128 / 256 / 512):
+//     y   = ELU(conv1x1x1(h) + b)                       reference magvit2_pytorch.py:938-940
+//     out = SqueezeExcite(y) + x                         reference :221-240 (per frame) and the Residual wrapper :944
+// It replaces the chains mv2_pw_se -> mv2_se_gate -> mv2_se_apply and mv2_pw_se -> mv2_se_rec_fc1 -> mv2_se_fc2_apply.  Why: at
+// batch 1 those launches are latency chains, not work (tools/se_bench on MI355X: pw_se 11-14 us, gate 7-14 us, apply 4-12 us for
+// 6.6-105 MB of algorithmic traffic; a dependent launch costs ~5 us even when it does nothing), y makes a round trip through HBM, and
+// a ResidualUnit's tail costs 22-34 us next to a 25-75 us convolution.
+//
+// One workgroup = BP rows x all C channels, as in pwse.hip (same GEMM, same record arithmetic).  What is new is that the workgroup does
+// not end after its record: the output tile stays in LDS, the workgroup publishes its pooling record, waits until every workgroup of
+// its FRAME has published (the gate needs the frame's softmax-pooled channel means), computes the frame's gate itself from the
+// records (R records of C + 4 floats; fc1 / fc2 with bf16 weights — what the reference's own bf16 autocast does to these 1x1 convs),
+// applies it to the tile in LDS, adds the residual (prefetched into registers while waiting) and stores.
+//
+// Cross-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility", cdna_hip_programming.md G16):
+//   * tiles are handed out by an atomic counter at workgroup START (frame-major), not by blockIdx: whatever the dispatch order and
+//     however few workgroups are resident, every tile of the earliest unfinished frame is owned by a workgroup that is already
+//     running, so that frame completes and its workgroups retire — no residency requirement, no deadlock;
+//   * records travel with 16-byte write-through (sc1) stores, drained (s_waitcnt vmcnt(0)) before the arrival atomic, and are read
+//     with sc1 loads after the poll: no L2 write-back / invalidate fence on either side (the form conv3.hip uses for its slabs);
+//   * ONE lane polls (relaxed agent-scope load + s_sleep), bounded: on expiry the error word is set and the workgroup proceeds
+//     (wrong values, no hang);
+//   * the last workgroup to retire zeroes the counters, so every launch (and every graph replay) starts from zeros.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "conv_common.h"
+#include "../../include/mv2.h"
+
+struct RuTailParams {
+    const void* in; const void* wp; const float* bias; const float* wk; float bk;
+    const unsigned short* w1t; const float* b1; const unsigned short* w2t; const float* b2;   // fc weights bf16: w1t[C][hidden], w2t[hidden][C]
+    const void* res; void* out; float* rec; uint32_t* sync;
+    int P, R, frames, hidden, ntiles;
+    uint32_t rec_bytes;
+};
+
+// sync words: [0] next tile, [1] retired workgroups, [2] error, [3] reserved, [4 + f] arrivals of frame f
+static constexpr int RT_SYNC_HDR = 4;
+static constexpr int RT_MAXR = 256;
+
+template <int CT, int PT> struct RuTailLds {
+    static constexpr int C = CT * 128, BP = PT * 32, PITCH = C * 2 + 16;
+    static constexpr int kTile = 0, kWk = BP * PITCH, kBias = kWk + C * 4, kLogit = kBias + C * 4, kEw = kLogit + BP * 4,
+                         kGrp = kEw + BP * 4,                 // 1024 floats: pooling groups, later the gate's partial-sum slab
+                         kRw = kGrp + 1024 * 4,               // RT_MAXR merge weights
+                         kPooled = kRw + RT_MAXR * 4,         // C
+                         kHid = kPooled + C * 4,              // hidden <= 256
+                         kGate = kHid + 256 * 4,              // C
+                         kMisc = kGate + C * 4,               // tile id, red[8]
+                         kBytes = kMisc + 64;
+};
+
+template <int CT, int PT>
+__global__ __launch_bounds__(256) void ru_tail_kernel(const RuTailParams p) {
+    typedef RuTailLds<CT, PT> L;
+    constexpr int C = L::C, BP = L::BP, PITCH = L::PITCH;
+    constexpr int KS = C / 16, D = (CT * PT >= 8) ? 4 : 8;
+    constexpr int CPR = C / 8, NLD = BP * CPR / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+
+    // ---- weights: first D k-steps on their way before anything else (they do not depend on the tile)
+    const char* wbase = (const char*)p.wp + (size_t)(wave * CT) * 4096 + lane * 16;
+    auto wfrag = [&](int ks, int ct) {
+        return *(const i32x4*)(wbase + ((size_t)(ks >> 2) * (C / 32) + ct) * 4096 + (ks & 3) * 1024);
+    };
+    i32x4 wf[D][CT];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) wf[d][ct] = wfrag(d, ct);
+
+    // ---- this workgroup's tile: handed out in start order, frame-major
+    uint32_t* misc = (uint32_t*)(smem + L::kMisc);
+    if (tid == 0) misc[0] = __hip_atomic_fetch_add(p.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = tid; c < C; c += 256) {
+        ((float*)(smem + L::kWk))[c] = p.wk[c];
+        ((float*)(smem + L::kBias))[c] = p.bias[c];
+    }
+    __syncthreads();
+    const uint32_t tile = misc[0];
+    if (tile >= (uint32_t)p.ntiles) return;              // cannot happen (grid == ntiles); keeps a bad launch from scribbling
+    const int64_t row0 = (int64_t)tile * BP;
+    const int f = (int)(row0 / p.P), j = (int)((row0 - (int64_t)f * p.P) / BP);
+
+    // ---- input tile -> LDS
+    {
+        i32x4 v[NLD];
+        const char* src = (const char*)p.in + row0 * C * 2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) v[i] = *(const i32x4*)(src + (size_t)(tid + 256 * i) * 16);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + 256 * i, row = q / CPR, ch = q % CPR;
+            *(i32x4*)(smem + row * PITCH + ch * 16) = v[i];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        i32x4 b[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) b[pt] = *(const i32x4*)(smem + (pt * 32 + l31) * PITCH + ks * 32 + hi * 16);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) Mma<BF16>::run(wf[ks % D][ct], b[pt], acc[ct][pt]);
+        if (ks + D < KS) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[ks % D][ct] = wfrag(ks + D, ct);
+        }
+    }
+    __syncthreads();                                     // every wave has read the input tile: it becomes the output tile
+
+    // ---- bias + ELU -> bf16 tile (the rounding the three-launch form applies when it stores y)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = (wave * CT + ct) * 32 + 8 * g + 4 * hi;
+            const f32x4 bv = *(const f32x4*)(smem + L::kBias + col * 4);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                float v[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = Act<BF16>::elu(acc[ct][pt][4 * g + jj] + bv[jj]);
+                lds_put4<BF16>(smem + (pt * 32 + l31) * PITCH + col * 2, v);
+            }
+        }
+    __syncthreads();
+
+    // ---- SqueezeExcite record of these BP rows: {max logit, sum exp, 0, 0, exp-weighted channel sums[C]}
+    constexpr int TPP = 256 / BP;
+    {
+        const int row = tid / TPP, q = tid % TPP;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPR / TPP; ++i) {
+            const int ch = q + TPP * i;
+            float xv[8];
+            Chunk<BF16>::unpack(*(const i32x4*)(smem + row * PITCH + ch * 16), xv);
+            const f32x4 w0 = *(const f32x4*)(smem + L::kWk + ch * 32), w1 = *(const f32x4*)(smem + L::kWk + ch * 32 + 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot += xv[k] * w0[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot += xv[4 + k] * w1[k];
+        }
+#pragma unroll
+        for (int o = 1; o < TPP; o <<= 1) dot += __shfl_xor(dot, o, 64);
+        if (q == 0) ((float*)(smem + L::kLogit))[row] = dot + p.bk;
+    }
+    __syncthreads();
+    float M = -INFINITY;
+    {
+        const float* lg = (const float*)(smem + L::kLogit);
+#pragma unroll
+        for (int r = 0; r < BP; r += 4) {
+            const f32x4 v = *(const f32x4*)(lg + r);
+            M = fmaxf(M, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        }
+        if (tid < BP) ((float*)(smem + L::kEw))[tid] = expf(lg[tid] - M);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)p.rec, 0, p.rec_bytes, 0x00020000);
+    const uint32_t rec_stride = (uint32_t)(C + 4) * 4u;
+    const float* ew = (const float*)(smem + L::kEw);
+    float* grp = (float*)(smem + L::kGrp);
+    {
+        constexpr int NG = 512 / C;                      // row groups when there are fewer channel pairs than threads
+        const int cp = tid % (C / 2), g = tid / (C / 2);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+        for (int r = g; r < BP; r += NG) {
+            const unsigned w = *(const unsigned*)(smem + r * PITCH + cp * 4);
+            const float e = ew[r];
+            a0 += e * __uint_as_float(w << 16);
+            a1 += e * __uint_as_float(w & 0xffff0000u);
+        }
+        *(f32x2*)(grp + g * C + 2 * cp) = f32x2{a0, a1};
+    }
+    __syncthreads();
+    {
+        constexpr int NG = 512 / C;
+        const uint32_t base = (uint32_t)((int64_t)f * p.R + j) * rec_stride;
+        if (tid < C / 4) {                               // one 16-byte write-through store per four channels
+            f32x4 a = *(const f32x4*)(grp + 4 * tid);
+#pragma unroll
+            for (int q = 1; q < NG; ++q) { const f32x4 t = *(const f32x4*)(grp + q * C + 4 * tid); a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3]; }
+            i32x4 vv = {__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(vv, rs_rec, (int)(base + 16u + (uint32_t)tid * 16u), 0, 16 /* sc1 */);
+        } else if (tid == 255) {
+            float s = 0.f;
+            for (int r = 0; r < BP; ++r) s += ew[r];
+            i32x4 vv = {__float_as_int(M), __float_as_int(s), 0, 0};
+            __builtin_amdgcn_raw_buffer_store_b128(vv, rs_rec, (int)base, 0, 16 /* sc1 */);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the arrival is counted
+    __syncthreads();
+
+    // ---- frame rendezvous: count this workgroup in, wait for the other R - 1.  The residual tile flies meanwhile (issued AFTER the
+    // drain above, so the arrival does not wait for it).
+    if (tid == 0) __hip_atomic_fetch_add(p.sync + RT_SYNC_HDR + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i32x4 rv[NLD];
+    {
+        const char* rsrc = (const char*)p.res + row0 * C * 2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) rv[i] = *(const i32x4*)(rsrc + (size_t)(tid + 256 * i) * 16);
+    }
+    if (tid == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(p.sync + RT_SYNC_HDR + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)p.R) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { __hip_atomic_store(p.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+
+    // ---- gate of frame f from its R records (every workgroup of the frame computes it: a few KB of records, bf16 weights from L2)
+    const int R = p.R, hidden = p.hidden;
+    float* rw = (float*)(smem + L::kRw);
+    float* red = (float*)(smem + L::kMisc) + 4;
+    const uint32_t fbase = (uint32_t)((int64_t)f * R) * rec_stride;
+    float mr = -INFINITY, sr = 0.f;
+    if (tid < R) {
+        const i32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(fbase + (uint32_t)tid * rec_stride), 0, 16 /* sc1 */);
+        mr = __int_as_float(h4[0]); sr = __int_as_float(h4[1]);
+    }
+    {
+        const float wm = wave_max(mr);
+        if (lane == 0) red[wave] = wm;
+    }
+    __syncthreads();
+    const float Mf = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    {
+        const float w = (tid < R && mr != -INFINITY) ? expf(mr - Mf) : 0.f;
+        if (tid < R) rw[tid] = w;
+        const float ws = wave_sum(sr * w);
+        if (lane == 0) red[4 + wave] = ws;
+    }
+    __syncthreads();
+    const float inv_s = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    {   // pooled[c]: threads (16-byte channel chunk, record slice)
+        constexpr int NCH = C / 4, RS = 256 / NCH;
+        const int ch = tid % NCH, rs = tid / NCH;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        int r = rs;
+        for (; r + 3 * RS < R; r += 4 * RS) {            // four loads in flight
+            i32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(fbase + (uint32_t)(r + u * RS) * rec_stride + 16u + (uint32_t)ch * 16u), 0, 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const float w = rw[r + u * RS];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] += w * __int_as_float(v[u][k]); }
+        }
+        for (; r < R; r += RS) {
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(fbase + (uint32_t)r * rec_stride + 16u + (uint32_t)ch * 16u), 0, 16);
+            const float w = rw[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += w * __int_as_float(v[k]);
+        }
+        *(f32x4*)(grp + rs * C + 4 * ch) = a;
+        __syncthreads();
+        if (tid < NCH) {
+            f32x4 o = *(const f32x4*)(grp + 4 * tid);
+#pragma unroll
+            for (int q = 1; q < RS; ++q) { const f32x4 t = *(const f32x4*)(grp + q * C + 4 * tid); o[0] += t[0]; o[1] += t[1]; o[2] += t[2]; o[3] += t[3]; }
+            o[0] *= inv_s; o[1] *= inv_s; o[2] *= inv_s; o[3] *= inv_s;
+            *(f32x4*)(smem + L::kPooled + 16 * tid) = o;
+        }
+        __syncthreads();
+    }
+    const float* pooled = (const float*)(smem + L::kPooled);
+    float* hid = (float*)(smem + L::kHid);
+    {   // hid[k] = lrelu(b1[k] + sum_c w1t[c][k] pooled[c]): threads (pair of hidden units, channel slice)
+        const int hp = hidden >> 1, KSL = 256 / hp;      // hidden = C / 2 -> hp = 32 / 64 / 128, 8 / 4 / 2 channel slices
+        const int kp = tid % hp, cs = tid / hp;
+        const int per = C / KSL, c0 = cs * per;
+        float a0 = 0.f, a1 = 0.f;
+        const unsigned* wrow = (const unsigned*)p.w1t + kp;
+#pragma unroll 1
+        for (int c = c0; c < c0 + per; c += 16) {
+            unsigned w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wrow[(size_t)(c + u) * hp];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float x = pooled[c + u]; a0 += __uint_as_float(w[u] << 16) * x; a1 += __uint_as_float(w[u] & 0xffff0000u) * x; }
+        }
+        *(f32x2*)(grp + cs * hidden + 2 * kp) = f32x2{a0, a1};
+        __syncthreads();
+        if (tid < hidden) {
+            float a = p.b1[tid];
+            for (int q = 0; q < KSL; ++q) a += grp[q * hidden + tid];
+            hid[tid] = a > 0.f ? a : 0.1f * a;
+        }
+        __syncthreads();
+    }
+    {   // gate[c] = sigmoid(b2[c] + sum_k w2t[k][c] hid[k]): threads (pair of channels, hidden slice)
+        constexpr int CP = C / 2, GS = 256 / CP;         // 64 / 128 / 256 channel pairs -> 4 / 2 / 1 slices
+        const int cp = tid % CP, ks = tid / CP;
+        const int per = hidden / GS, k0 = ks * per;
+        float a0 = 0.f, a1 = 0.f;
+        const unsigned* wcol = (const unsigned*)p.w2t + cp;
+#pragma unroll 1
+        for (int k = k0; k < k0 + per; k += 16) {
+            unsigned w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wcol[(size_t)(k + u) * CP];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float x = hid[k + u]; a0 += __uint_as_float(w[u] << 16) * x; a1 += __uint_as_float(w[u] & 0xffff0000u) * x; }
+        }
+        *(f32x2*)(grp + ks * C + 2 * cp) = f32x2{a0, a1};
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = p.b2[c];
+#pragma unroll
+            for (int q = 0; q < GS; ++q) a += grp[q * C + c];
+            ((float*)(smem + L::kGate))[c] = 1.f / (1.f + expf(-a));
+        }
+        __syncthreads();
+    }
+
+    // ---- out = gate * y + residual, whole rows in 16-byte chunks
+    {
+        char* dst = (char*)p.out + row0 * C * 2;
+        const float* gate = (const float*)(smem + L::kGate);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + 256 * i, row = q / CPR, ch = q % CPR;
+            float a[8], r[8];
+            Chunk<BF16>::unpack(*(const i32x4*)(smem + row * PITCH + ch * 16), a);
+            Chunk<BF16>::unpack(rv[i], r);
+            const f32x4 g0 = *(const f32x4*)(gate + ch * 8), g1 = *(const f32x4*)(gate + ch * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = a[k] * g0[k] + r[k]; a[4 + k] = a[4 + k] * g1[k] + r[4 + k]; }
+            *(i32x4*)(dst + (size_t)q * 16) = Chunk<BF16>::pack(a);
+        }
+    }
+
+    // ---- retire; the last workgroup of the launch leaves the counters zero for the next launch / replay
+    if (tid == 0) {
+        const uint32_t d = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == (uint32_t)p.ntiles - 1u) {
+            for (int ff = 0; ff < p.frames; ++ff) __hip_atomic_store(p.sync + RT_SYNC_HDR + ff, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static int ru_tail_bp(int dtype, int64_t rows, int P, int C, int hidden) {
+    if (dtype != MV2_BF16 || rows <= 0 || P <= 0 || rows % P != 0) return 0;
+    if (C != 128 && C != 256 && C != 512) return 0;
+    if (hidden != C / 2) return 0;                       // the thread maps of the gate assume the reference's dim_hidden = dim / 2 (M:207)
+    int bp = 0;
+    if (P % 64 == 0 && rows / 64 >= 512) bp = 64;        // enough 64-row workgroups to fill the chip twice
+    else if (P % 32 == 0) bp = 32;
+    if (!bp || P / bp > RT_MAXR) return 0;
+    return bp;
+}
+
+// rows per workgroup (= rows per pooling record); 0 = not eligible (the caller keeps the multi-launch form)
+extern "C" int mv2_ru_tail_rows(int dtype, int64_t rows, int P, int C, int hidden) { return ru_tail_bp(dtype, rows, P, C, hidden); }
+
+extern "C" size_t mv2_ru_tail_rec_bytes(int64_t rows, int P, int C, int bp) {
+    if (rows <= 0 || P <= 0 || bp <= 0) return 0;
+    return (size_t)(rows / bp) * (size_t)(C + 4) * sizeof(float);
+}
+extern "C" size_t mv2_ru_tail_sync_bytes(int frames) { return (size_t)(RT_SYNC_HDR + (frames > 0 ? frames : 0)) * sizeof(uint32_t); }
+
+extern "C" int mv2_ru_tail(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk,
+                           const void* se_w1t_bf16, const float* se_b1, const void* se_w2t_bf16, const float* se_b2,
+                           const void* residual, void* out, float* rec, size_t rec_bytes, void* sync, size_t sync_bytes,
+                           int64_t rows, int P, int C, int hidden, void* stream) {
+    if (!in || !wp || !bias || !se_wk || !se_w1t_bf16 || !se_b1 || !se_w2t_bf16 || !se_b2 || !residual || !out || !rec || !sync) return MV2_EINVAL;
+    if ((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)rec) & 15) || ((uintptr_t)sync & 3)) return MV2_EINVAL;
+    if ((((uintptr_t)se_w1t_bf16 | (uintptr_t)se_w2t_bf16) & 3)) return MV2_EINVAL;
+    const int bp = ru_tail_bp(dtype, rows, P, C, hidden);
+    if (!bp) return MV2_EINVAL;
+    const int64_t ntiles = rows / bp, frames = rows / P;
+    if (ntiles >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
+    const size_t need = mv2_ru_tail_rec_bytes(rows, P, C, bp);
+    if (rec_bytes < need || need >= 0xfffffff0ull) return MV2_EWORKSPACE;
+    if (sync_bytes < mv2_ru_tail_sync_bytes((int)frames)) return MV2_EWORKSPACE;
+    RuTailParams p{in, wp, bias, se_wk, se_bk, (const unsigned short*)se_w1t_bf16, se_b1, (const unsigned short*)se_w2t_bf16, se_b2,
+                   residual, out, rec, (uint32_t*)sync, P, P / bp, (int)frames, hidden, (int)ntiles, (uint32_t)need};
+    const dim3 grid((unsigned)ntiles);
+    hipStream_t st = (hipStream_t)stream;
+#define RU_TAIL(CTv, PTv)                                                                                                  \
+    do {                                                                                                                  \
+        const int lds = RuTailLds<CTv, PTv>::kBytes;                                                                      \
+        if (hipFuncSetAttribute((const void*)ru_tail_kernel<CTv, PTv>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+            return MV2_ENODEVICE;                                                                                         \
+        hipLaunchKernelGGL((ru_tail_kernel<CTv, PTv>), grid, dim3(256), lds, st, p);                                      \
+    } while (0)
+    if (bp == 64) { if (C == 128) RU_TAIL(1, 2); else if (C == 256) RU_TAIL(2, 2); else RU_TAIL(4, 2); }
+    else { if (C == 128) RU_TAIL(1, 1); else if (C == 256) RU_TAIL(2, 1); else RU_TAIL(4, 1); }
+#undef RU_TAIL
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

@@ -68,6 +68,9 @@ class PackedModel:
             self.f32[pre + '.se.b1'] = dev(f(pre + '.fn.4.net.0.bias'))
             self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous())
             self.f32[pre + '.se.b2'] = dev(f(pre + '.fn.4.net.2.bias'))
+            if (pre + '.k1') in self.frag:                               # mv2_ru_tail reads the two fc weight matrices in bf16
+                self.frag[pre + '.se.w1'] = dev(f(pre + '.fn.4.net.0.weight').flatten(1).t().contiguous().to(torch.bfloat16))
+                self.frag[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous().to(torch.bfloat16))
 
         def adaptive(pre, dim):
             # AdaptiveRMSNorm (reference M:278-323): gamma = to_gamma(cond) is per sample, so only sqrt(dim) folds into the weights
@@ -381,6 +384,15 @@ class Plan:
             self.arena.put(ws)
         return out, pw_part
 
+    def _ru_sync(self, nbytes):
+        """One zero-initialised counter block shared by every mv2_ru_tail launch of the plan (each launch leaves it zero)."""
+        n = (int(nbytes) + 3) // 4
+        if getattr(self, '_ru_sync_buf', None) is None:
+            cap = 4 + self.B * (self.T + self.time_padding)             # header + one arrival word per frame at the full frame count
+            self._ru_sync_buf = self.ops.zeros((max(cap, n),), torch.int32)
+        assert self._ru_sync_buf.numel() >= n, 'ru_tail counter block too small for this level'
+        return self._ru_sync_buf
+
     def _tickets(self, nbytes):
         """One zero-initialised ticket buffer shared by every mv2_conv3 launch of the plan (each launch leaves it zero)."""
         n = (int(nbytes) + 3) // 4
@@ -414,8 +426,25 @@ class Plan:
             bp = 0
             if not fuse and (pre + '.k1') in pm.frag and not os.environ.get('MV2_NO_PW_SE'):
                 bp = ops.pw_se_rows(self.dt, x.rows, Pn, C)
+            rt = 0
+            if bp and not os.environ.get('MV2_NO_RU_TAIL'):
+                rt = ops.ru_tail_rows(self.dt, x.rows, Pn, C, hidden)
             if fuse:
                 y2 = y1
+            elif rt:
+                # conv1 + ELU + SqueezeExcite + residual in ONE launch (rutail.hip): the workgroups of a frame meet inside the launch
+                out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
+                rec_bytes, sync_bytes = ops.ru_tail_sizes(x.rows, Pn, C, rt)
+                rec = self.arena.get((rec_bytes + 3) // 4, torch.float32)
+                steps.append(ops.ru_tail(self.dt, y1.t, pm.frag[pre + '.k1'], pc1.bias, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']),
+                                         pm.frag[pre + '.se.w1'], pm.f32[pre + '.se.b1'], pm.frag[pre + '.se.w2'], pm.f32[pre + '.se.b2'],
+                                         x.t, out.t, rec, self._ru_sync(sync_bytes), x.rows, Pn, C, hidden))
+                steps[-1].label = pre + '.k1+se'
+                self.step_flops[id(steps[-1])] = 2.0 * x.rows * C * C
+                self.step_names.append(pre + '.k1+se')
+                for t in (rec, y1.t, x.t):
+                    self.arena.put(t)
+                return out
             elif bp:
                 # conv1 + ELU + SqueezeExcite pooling records in one launch (pwse.hip); the gate + apply launches follow
                 y2 = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)

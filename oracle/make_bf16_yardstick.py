@@ -50,12 +50,23 @@ def main():
                 c32, r32 = ref(v, return_codes=True, return_recon=True)
                 with torch.autocast('cpu', dtype=torch.bfloat16):
                     c16, r16 = ref(v, return_codes=True, return_recon=True)
+                # the two SMOOTH halves (no id flips involved): the encoder up to the quantizer's projection, and the decoder teacher-forced
+                # with the fp32 ids — what the GPU test's regression gates are taken on
+                z32 = ref.quantizers.project_in(ref.encode(v).movedim(1, -1))
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    z16 = ref.quantizers.project_in(ref.encode(v).movedim(1, -1))
+                    d16 = ref.decode_from_code_indices(c32)
             d = (r16.float() - r32).abs()
-            rows.append(dict(data_seed=ds, ids_mismatch=float((c16 != c32).float().mean()), recon_mean_abs=float(d.mean()), recon_max_abs=float(d.max())))
+            dd = (d16.float() - r32).abs()
+            dz = (z16.float() - z32).abs()
+            rows.append(dict(data_seed=ds, ids_mismatch=float((c16 != c32).float().mean()), recon_mean_abs=float(d.mean()), recon_max_abs=float(d.max()),
+                             decoder_only_mean_abs=float(dd.mean()), prequant_mean_abs=float(dz.mean()), prequant_ref_mean_abs_value=float(z32.abs().mean())))
             print(name, rows[-1], f'{time.time() - t0:.1f}s', flush=True)
         n = len(rows)
         res['cases'][name] = dict(kw={k: (list(x) if isinstance(x, tuple) else x) for k, x in kw.items()}, shape=list(shape), weight_seed=wseed, rows=rows,
-                                  mean_ids_mismatch=sum(r['ids_mismatch'] for r in rows) / n, mean_recon_mean_abs=sum(r['recon_mean_abs'] for r in rows) / n)
+                                  mean_ids_mismatch=sum(r['ids_mismatch'] for r in rows) / n, mean_recon_mean_abs=sum(r['recon_mean_abs'] for r in rows) / n,
+                                  mean_decoder_only_mean_abs=sum(r['decoder_only_mean_abs'] for r in rows) / n,
+                                  mean_prequant_mean_abs=sum(r['prequant_mean_abs'] for r in rows) / n)
         with open(OUT, 'w') as f:
             json.dump(res, f, indent=1)
     print('wrote', OUT)
