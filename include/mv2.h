@@ -114,6 +114,15 @@ int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void
              const float* bias, const float* rowscale, const void* residual, void* out,
              void* workspace, size_t workspace_bytes, void* stream);
 
+/* mv2_conv with the RMSNorm row scale computed INSIDE the launch (reference RMSNorm M:258-276: x / max(|x|, 1e-12) per position, the
+ * gamma * sqrt(dim) factor being folded into the packed weights): rowscale[m] = 1 / max(|gathered row m|, 1e-12) over the whole
+ * reduction extent, taken from the rows the GEMM stages anyway — one launch and one pass over x less than mv2_rms_rowscale + mv2_conv.
+ * Needs the reduction extent to be exactly the row (no zero-padded K tail: nsteps * 128 bytes == taps * Ci * elem bytes — the caller's
+ * responsibility) and mv2_conv_rms_ok(desc) == 1 (no split-K for this shape, staged 16-byte stores). */
+int mv2_conv_rms_ok(const mv2_conv_desc* desc);
+int mv2_conv_rms(const mv2_conv_desc* desc, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                 const float* bias, const void* residual, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * mv2_conv3 — the ResidualUnit convolution: stride-1 kt x 3 x 3 (kt <= 3) causal-in-time / "same"-in-space
  * CausalConv3d over whole 128-byte channel chunks, C_out >= 64.
@@ -295,26 +304,6 @@ int mv2_gateloop_scan(int dtype, const void* qkva, const void* residual, void* o
 int mv2_pw_se_rows(int dtype, int64_t rows, int P, int C);
 int mv2_pw_se(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk, void* out,
               float* se_part, int64_t rows, int P, int C, void* stream);
-
-/* The WHOLE tail of a ResidualUnit at C = 128 / 256 / 512, bf16, in ONE launch (rutail.hip): y = ELU(conv1x1x1(h) + b) (reference
- * M:938-940), out = SqueezeExcite(y) + x (M:221-240 per frame, Residual M:944).  Replaces mv2_pw_se -> mv2_se_gate -> mv2_se_apply
- * (and the rec_fc1 / fc2_apply form): the output tile never leaves LDS; workgroups of one frame meet through pooling records and an
- * arrival counter inside the launch (tiles are handed out at workgroup start, so there is no residency requirement).
- *   in / residual / out : rows x C bf16 (out may alias residual; must not alias in)
- *   wp                  : the C x C 1x1x1 kernel, fragment-major (as mv2_pw_se)
- *   se_w1t_bf16         : [C][hidden] bf16 = net[0].weight transposed; se_w2t_bf16: [hidden][C] bf16 = net[2].weight transposed
- *                         (bf16: what the reference's own bf16 autocast does to these 1x1 convs); biases fp32; hidden must be C / 2
- *   rec                 : workspace, mv2_ru_tail_rec_bytes(rows, P, C, mv2_ru_tail_rows(...)) bytes (records of C + 4 floats)
- *   sync                : mv2_ru_tail_sync_bytes(rows / P) bytes, ZERO before the first launch; every launch leaves it zero
- *                         (word 2 is an error flag: set when a bounded wait expired — results are then invalid)
- * mv2_ru_tail_rows: rows per workgroup (32 or 64), 0 when the shape is not eligible (the caller keeps the multi-launch form). */
-int mv2_ru_tail_rows(int dtype, int64_t rows, int P, int C, int hidden);
-size_t mv2_ru_tail_rec_bytes(int64_t rows, int P, int C, int rows_per_workgroup);
-size_t mv2_ru_tail_sync_bytes(int frames);
-int mv2_ru_tail(int dtype, const void* in, const void* wp, const float* bias, const float* se_wk, float se_bk,
-                const void* se_w1t_bf16, const float* se_b1, const void* se_w2t_bf16, const float* se_b2,
-                const void* residual, void* out, float* rec, size_t rec_bytes, void* sync, size_t sync_bytes,
-                int64_t rows, int P, int C, int hidden, void* stream);
 
 /* Training-mode LFQ (third-party LFQ.forward with self.training, reference call site M:1705, loss weights M:1067-1072, recon loss
  * M:1722).  mv2_lfq_train = mv2_lfq with the straight-through forward value z + (q - z) (prequant is mandatory: it feeds

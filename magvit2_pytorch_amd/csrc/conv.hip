@@ -71,7 +71,18 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     // LDS: the eight lanes of a row used to repeat three 64-bit divisions for each of their RP rows, which was a
     // ~1200-instruction prologue -- most of the fixed ~15 us floor of the small launches.
     uint32_t rowbase[RP], rowmask[RP];
-    {
+    // 1x1x1, stride 1, no padding: input row == output row, nothing to decode and nothing to mask.  The table + two barriers below are
+    // ~2 us of a launch whose whole K loop is 4-22 steps (the feed-forward / projection / up-sampling GEMMs: 30 launches per clip).
+    const bool linear_rows = d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0 &&
+                             d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi;
+    if (linear_rows) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int64_t m = m0 + r0 + 32 * i;
+            rowbase[i] = (uint32_t)m * (uint32_t)d.Ci * (uint32_t)E::kBytes;
+            rowmask[i] = m < p.M ? 0x00ffffffu : 0u;
+        }
+    } else {
         uint32_t* tab = (uint32_t*)smem;        // [BPOS][2]; LDS is idle before the K loop
         for (int r = tid; r < BPOS; r += 256) {
             const int64_t m = m0 + r;
@@ -128,6 +139,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     // step s computes and step s+1 (issued one step earlier) is written to the other LDS buffer, so every
     // gather has two steps of flight time before it is waited for.
     i32x4 gw[2][RW], gp[2][RP];
+    float rss[RP];                  // rms_fused: this thread's share (one 16-byte chunk per step) of the sum of squares of its RP rows
+#pragma unroll
+    for (int i = 0; i < RP; ++i) rss[i] = 0.f;
 
     // NB every load below is issued UNCONDITIONALLY (steps past the end read the out-of-range offset: zeros,
     // no traffic).  A load inside a branch makes the wait-count pass fall back to vmcnt(0) at the next LDS
@@ -155,6 +169,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         for (int i = 0; i < RW; ++i) *(i32x4*)(base + lds_wr + i * 32 * 128) = gw[PAR][i];
 #pragma unroll
         for (int i = 0; i < RP; ++i) *(i32x4*)(base + BCO * 128 + lds_wr + i * 32 * 128) = gp[PAR][i];
+        if (p.rms_fused) {          // every staged chunk passes here exactly once (the dummy behind the last step is zeros)
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                float f[8];
+                Chunk<E>::unpack(gp[PAR][i], f);
+#pragma unroll
+                for (int j = 0; j < E::kVec; ++j) rss[i] += f[j] * f[j];
+            }
+        }
     };
 
     if (s_begin < s_end) {
@@ -234,7 +257,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         return;
     }
     if (stage_ok(p)) {   // LDS-staged, fully coalesced stores (the K loop ended on a barrier: LDS is free)
-        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; });
+        if (p.rms_fused) {   // the eight lanes of a row hold its eight chunk columns: fold, then one lane per row publishes 1 / |row|
+            float* rs_lds = (float*)(smem + StageCfg<E, BCO, BPOS>::kRowScale);
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                float ss = rss[i];
+                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                if (c == 0) rs_lds[r0 + 32 * i] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            }
+        }
+        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; }, true, p.rms_fused != 0);
         CV_PROF(2)
         CV_PROF_END
         return;
@@ -446,9 +478,35 @@ extern "C" size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d) {
     return (size_t)L.splitk * (size_t)L.ws_rows * (size_t)L.ws_cols * sizeof(float);
 }
 
+static int conv_impl(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                     const float* bias, const float* rowscale, const void* residual, void* out,
+                     void* workspace, size_t workspace_bytes, void* stream, int rms_fused);
+
 extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                         const float* bias, const float* rowscale, const void* residual, void* out,
                         void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_impl(d, in, in_bytes, wp, segs, bias, rowscale, residual, out, workspace, workspace_bytes, stream, 0);
+}
+
+// 1 when mv2_conv_rms can run this descriptor: the launch keeps the whole reduction extent in one workgroup (no split-K) and stores
+// through the staged epilogue (rows / depth-to-space stores with 16-byte chunks)
+extern "C" int mv2_conv_rms_ok(const mv2_conv_desc* d) {
+    if (!d || validate(*d) != MV2_OK) return 0;
+    if (d->store == MV2_STORE_NCTHW_F32) return 0;
+    const int es = d->dtype == MV2_BF16 ? 2 : 4;
+    if (((d->out_c * es) % 16) != 0 || (d->co % (16 / es)) != 0) return 0;
+    return plan_launch(*d).splitk == 1 ? 1 : 0;
+}
+
+extern "C" int mv2_conv_rms(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                            const float* bias, const void* residual, void* out, void* stream) {
+    if (!mv2_conv_rms_ok(d)) return MV2_EINVAL;
+    return conv_impl(d, in, in_bytes, wp, segs, bias, nullptr, residual, out, nullptr, 0, stream, 1);
+}
+
+static int conv_impl(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
+                     const float* bias, const float* rowscale, const void* residual, void* out,
+                     void* workspace, size_t workspace_bytes, void* stream, int rms_fused) {
     if (!d || !in || !wp || !segs || !out) return MV2_EINVAL;
     int rc = validate(*d);
     if (rc != MV2_OK) return rc;
@@ -465,6 +523,7 @@ extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes,
     p.wp2 = nullptr; p.bias2 = nullptr; p.act2 = MV2_ACT_NONE;
     p.se_wk = nullptr; p.se_bk = 0.f; p.se_part = nullptr;
     p.counters = nullptr; p.gtot = 0;
+    p.rms_fused = rms_fused;
     p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.M = L.M; p.lg_seg_chunks = ilog2(d->seg_bytes / 16);
     p.n_co_tiles = L.n_co_tiles; p.n_pos_tiles = L.n_pos_tiles;

@@ -41,6 +41,9 @@ struct ConvParams {
     uint32_t gtot;        // units of the work list (groups + delta virtual units per tile)
     uint32_t delta;
     uint32_t ws_bytes;
+    // mv2_conv_rms: the per-row scale 1 / |gathered row| (RMSNorm, reference M:258-276) is computed inside the GEMM launch from the rows
+    // it stages anyway; `rowscale` is null
+    int32_t rms_fused;
 };
 
 
@@ -159,7 +162,7 @@ __device__ __forceinline__ bool stage_ok(const ConvParams& p) {
 // only help with the row stores of phase 2
 template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typename RowFn>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
-                                                int wpos, int tid, RowFn row_of, bool owner = true) {
+                                                int wpos, int tid, RowFn row_of, bool owner = true, bool rs_in_lds = false) {
     const mv2_conv_desc& d = p.d;
     typedef StageCfg<E, BCO, BPOS> SC;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
             }
         }
         rowtab[lp] = dr;
-        rs_lds[lp] = (valid && p.rowscale) ? p.rowscale[m] : 1.f;
+        if (!rs_in_lds) rs_lds[lp] = (valid && p.rowscale) ? p.rowscale[m] : 1.f;     // rs_in_lds: the caller has put the scales there
     }
     for (int q = tid; q < BCO; q += NT) bias_lds[q] = (p.bias && n0 + q < d.co_pad) ? p.bias[n0 + q] : 0.f;
     __syncthreads();

@@ -37,6 +37,8 @@ _SIGS = {
     'mv2_conv_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_conv_rms_ok': (C.c_int, [C.POINTER(ConvDesc)]),
+    'mv2_conv_rms': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mv2_conv3_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv3_fusable': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv3_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
@@ -66,11 +68,6 @@ _SIGS = {
     'mv2_pw_se_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     'mv2_pw_se': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.c_int, C.c_void_p]),
-    'mv2_ru_tail_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
-    'mv2_ru_tail_rec_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
-    'mv2_ru_tail_sync_bytes': (C.c_size_t, [C.c_int]),
-    'mv2_ru_tail': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p, C.c_size_t,
-                              C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq_train': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'mv2_lfq_stats_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     'mv2_lfq_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -167,6 +164,16 @@ class HipOps:
 
         return _mk(fn, args, 'mv2_conv', keep, [out, ws])
 
+    def conv_rms_ok(self, d: dict) -> bool:
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv_rms_ok(C.byref(desc)))
+
+    def conv_rms(self, d: dict, x, in_bytes, wp, segs, bias, residual, out):
+        desc = ConvDesc(**d)
+        fn = self.lib.mv2_conv_rms
+        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp), _ptr(segs), _ptr(bias), _ptr(residual), _ptr(out))
+        return _mk(fn, args, 'mv2_conv_rms', (desc, x, wp, segs, bias, residual, out), [out])
+
     def conv3_eligible(self, d: dict) -> bool:
         desc = ConvDesc(**d)
         return bool(self.lib.mv2_conv3_eligible(C.byref(desc)))
@@ -231,19 +238,6 @@ class HipOps:
         fn = self.lib.mv2_pw_se
         args = (dt, _ptr(x), _ptr(wp), _ptr(bias), _ptr(se_wk), float(se_bk), _ptr(out), _ptr(se_part), rows, Pn, Cc)
         return _mk(fn, args, 'mv2_pw_se', (x, wp, bias, se_wk, out, se_part), [out, se_part])
-
-    def ru_tail_rows(self, dt, rows, Pn, Cc, hidden) -> int:
-        return int(self.lib.mv2_ru_tail_rows(dt, rows, Pn, Cc, hidden))
-
-    def ru_tail_sizes(self, rows, Pn, Cc, bp):
-        """(record workspace bytes, sync bytes)"""
-        return int(self.lib.mv2_ru_tail_rec_bytes(rows, Pn, Cc, bp)), int(self.lib.mv2_ru_tail_sync_bytes(rows // Pn))
-
-    def ru_tail(self, dt, x, wp, bias, se_wk, se_bk, w1t16, b1, w2t16, b2, residual, out, rec, sync, rows, Pn, Cc, hidden):
-        fn = self.lib.mv2_ru_tail
-        args = (dt, _ptr(x), _ptr(wp), _ptr(bias), _ptr(se_wk), float(se_bk), _ptr(w1t16), _ptr(b1), _ptr(w2t16), _ptr(b2), _ptr(residual), _ptr(out),
-                _ptr(rec), rec.numel() * rec.element_size(), _ptr(sync), sync.numel() * sync.element_size(), rows, Pn, Cc, hidden)
-        return _mk(fn, args, 'mv2_ru_tail', (x, wp, bias, se_wk, w1t16, b1, w2t16, b2, residual, out, rec, sync), [out])
 
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
         fn, args = self.lib.mv2_video_to_ndhwc, (dt, _ptr(video), _ptr(out), B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems)

@@ -68,9 +68,6 @@ class PackedModel:
             self.f32[pre + '.se.b1'] = dev(f(pre + '.fn.4.net.0.bias'))
             self.f32[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous())
             self.f32[pre + '.se.b2'] = dev(f(pre + '.fn.4.net.2.bias'))
-            if (pre + '.k1') in self.frag:                               # mv2_ru_tail reads the two fc weight matrices in bf16
-                self.frag[pre + '.se.w1'] = dev(f(pre + '.fn.4.net.0.weight').flatten(1).t().contiguous().to(torch.bfloat16))
-                self.frag[pre + '.se.w2'] = dev(f(pre + '.fn.4.net.2.weight').flatten(1).t().contiguous().to(torch.bfloat16))
 
         def adaptive(pre, dim):
             # AdaptiveRMSNorm (reference M:278-323): gamma = to_gamma(cond) is per sample, so only sqrt(dim) folds into the weights
@@ -318,7 +315,9 @@ class Plan:
     # ------------------------------------------------------------------ helpers
     def _conv(self, steps, name, pc: P.PackedConv, x: Act, *, To=None, Ho=None, Wo=None, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
               check_bounds=True, act=P.ACT_NONE, store=P.STORE_ROWS, shuffle=(1, 1, 1), crop_t=0, out_c=None, rowscale=None,
-              residual=None, out_t=None, in_bytes=None, in_geom=None):
+              residual=None, out_t=None, in_bytes=None, in_geom=None, rms_shift=None):
+        """rms_shift (None / False / True): the launch is preceded by RMSNorm's row scale (True: of the TokenShift-ed row).  It is computed
+        inside the GEMM launch where the kernel can (mv2_conv_rms), by a separate mv2_rms_rowscale launch otherwise."""
         B, Ti, Hi, Wi, Ci = in_geom if in_geom is not None else (x.B, x.T, x.H, x.W, x.C)
         To = Ti if To is None else To
         Ho = Hi if Ho is None else Ho
@@ -339,6 +338,22 @@ class Plan:
                 out_t = self.arena.get(out_rows * out_c, self.dtype)
             out = Act(out_t, B, To * rt, Ho * rh, Wo * rw, out_c)
         segs = pc.segs_tensor(Hi, Wi, Ci, self.ops.device)
+        if rms_shift is not None:
+            assert rowscale is None
+            if self.ops.conv_rms_ok(d) and not os.environ.get('MV2_NO_CONV_RMS'):
+                if in_bytes is None:
+                    in_bytes = x.t.numel() * x.t.element_size()
+                steps.append(self.ops.conv_rms(d, x.t, in_bytes, pc.wp, segs, pc.bias, None if residual is None else residual.t, out_t))
+                steps[-1].label = name
+                self.step_flops[id(steps[-1])] = 2.0 * rows_out * pc.co_real * pc.k_real
+                self.step_names.append(name)
+                return out
+            rowscale = self._rms(steps, x, bool(rms_shift))
+            out_ = self._conv(steps, name, pc, x, To=To, Ho=Ho, Wo=Wo, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw, check_bounds=check_bounds, act=act,
+                              store=store, shuffle=shuffle, crop_t=crop_t, out_c=out_c, rowscale=rowscale, residual=residual, out_t=out_t,
+                              in_bytes=in_bytes, in_geom=in_geom)
+            self.arena.put(rowscale)
+            return out_
         wsb = self.ops.conv_workspace_bytes(d)
         ws = self.arena.get((wsb + 3) // 4, torch.float32) if wsb > 0 else None
         if in_bytes is None:
@@ -384,15 +399,6 @@ class Plan:
             self.arena.put(ws)
         return out, pw_part
 
-    def _ru_sync(self, nbytes):
-        """One zero-initialised counter block shared by every mv2_ru_tail launch of the plan (each launch leaves it zero)."""
-        n = (int(nbytes) + 3) // 4
-        if getattr(self, '_ru_sync_buf', None) is None:
-            cap = 4 + self.B * (self.T + self.time_padding)             # header + one arrival word per frame at the full frame count
-            self._ru_sync_buf = self.ops.zeros((max(cap, n),), torch.int32)
-        assert self._ru_sync_buf.numel() >= n, 'ru_tail counter block too small for this level'
-        return self._ru_sync_buf
-
     def _tickets(self, nbytes):
         """One zero-initialised ticket buffer shared by every mv2_conv3 launch of the plan (each launch leaves it zero)."""
         n = (int(nbytes) + 3) // 4
@@ -426,25 +432,8 @@ class Plan:
             bp = 0
             if not fuse and (pre + '.k1') in pm.frag and not os.environ.get('MV2_NO_PW_SE'):
                 bp = ops.pw_se_rows(self.dt, x.rows, Pn, C)
-            rt = 0
-            if bp and not os.environ.get('MV2_NO_RU_TAIL'):
-                rt = ops.ru_tail_rows(self.dt, x.rows, Pn, C, hidden)
             if fuse:
                 y2 = y1
-            elif rt:
-                # conv1 + ELU + SqueezeExcite + residual in ONE launch (rutail.hip): the workgroups of a frame meet inside the launch
-                out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
-                rec_bytes, sync_bytes = ops.ru_tail_sizes(x.rows, Pn, C, rt)
-                rec = self.arena.get((rec_bytes + 3) // 4, torch.float32)
-                steps.append(ops.ru_tail(self.dt, y1.t, pm.frag[pre + '.k1'], pc1.bias, pm.f32[pre + '.se.wk'], float(pm.f32[pre + '.se.bk']),
-                                         pm.frag[pre + '.se.w1'], pm.f32[pre + '.se.b1'], pm.frag[pre + '.se.w2'], pm.f32[pre + '.se.b2'],
-                                         x.t, out.t, rec, self._ru_sync(sync_bytes), x.rows, Pn, C, hidden))
-                steps[-1].label = pre + '.k1+se'
-                self.step_flops[id(steps[-1])] = 2.0 * x.rows * C * C
-                self.step_names.append(pre + '.k1+se')
-                for t in (rec, y1.t, x.t):
-                    self.arena.put(t)
-                return out
             elif bp:
                 # conv1 + ELU + SqueezeExcite pooling records in one launch (pwse.hip); the gate + apply launches follow
                 y2 = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
@@ -539,16 +528,16 @@ class Plan:
 
     def _feed_forward(self, steps, pre, x: Act, shift: bool, cond=None) -> Act:
         pm = self.pm
-        rs = self._rms(steps, x, shift)
         kw = dict(pt=1, check_bounds=True) if shift else dict(check_bounds=False)
-        xin = x
-        if cond is not None:
+        if cond is None:       # RMSNorm's row scale rides in the GEMM launch (mv2_conv_rms) where the kernel can
+            h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], x, act=P.ACT_GEGLU, rms_shift=shift, **kw)
+        else:                  # the scale is taken on x, the GEMM reads the modulated copy
+            rs = self._rms(steps, x, shift)
             xin, g = self._modulated(steps, pre + '.norm', x, cond, '.to_gamma.w', '.to_gamma.b', 0.)
             self.arena.put(g)
-        h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], xin, act=P.ACT_GEGLU, rowscale=rs, **kw)
-        if cond is not None:
+            h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], xin, act=P.ACT_GEGLU, rowscale=rs, **kw)
             self.arena.put(xin.t)
-        self.arena.put(rs)
+            self.arena.put(rs)
         out = self._conv(steps, pre + '.ff2', pm.convs[pre + '.ff2'], h, residual=x, check_bounds=False)
         self.arena.put(h.t)
         self.arena.put(x.t)
@@ -557,16 +546,16 @@ class Plan:
     def _attention(self, steps, pre, x: Act, time_axis: bool, cond=None) -> Act:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['attn_heads'], cfg['attn_dim_head']
-        rs = self._rms(steps, x, time_axis)
         kw = dict(pt=1, check_bounds=True) if time_axis else dict(check_bounds=False)
-        xin = x
-        if cond is not None:
+        if cond is None:
+            qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], x, rms_shift=time_axis, **kw)
+        else:
+            rs = self._rms(steps, x, time_axis)
             xin, g = self._modulated(steps, pre + '.norm', x, cond, '.to_gamma.w', '.to_gamma.b', 0.)
             self.arena.put(g)
-        qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], xin, rowscale=rs, **kw)
-        if cond is not None:
+            qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], xin, rowscale=rs, **kw)
             self.arena.put(xin.t)
-        self.arena.put(rs)
+            self.arena.put(rs)
         ao = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
         mem = pm.f32[pre + '.mem_kv']
         hw = x.H * x.W
@@ -586,9 +575,7 @@ class Plan:
         (gamma * sqrt(dim) in the weights, 1 / |x| as the epilogue rowscale), [q | kv | a] = one pointwise GEMM, then the gated
         scan along time with the residual add (mv2_gateloop_scan)."""
         pm, ops = self.pm, self.ops
-        rs = self._rms(steps, x, False)
-        qkva = self._conv(steps, pre + '.qkva', pm.convs[pre + '.qkva'], x, rowscale=rs, check_bounds=False)
-        self.arena.put(rs)
+        qkva = self._conv(steps, pre + '.qkva', pm.convs[pre + '.qkva'], x, rms_shift=False, check_bounds=False)
         out = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
         steps.append(ops.gateloop_scan(self.dt, qkva.t, x.t, out.t, x.B, x.T, x.H * x.W, x.C))
         self.step_names.append('gateloop_scan')
@@ -600,10 +587,8 @@ class Plan:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['linear_attn_heads'], cfg['linear_attn_dim_head']
         assert dh == 8, 'Taylor attention kernel is built for dim_head 8 (reference default, magvit2_pytorch.py:1079)'
-        rs = self._rms(steps, x, False)
-        q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rowscale=rs, check_bounds=False)
-        kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rowscale=rs, check_bounds=False)
-        self.arena.put(rs)
+        q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
+        kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
         frames, n = x.B * x.T, x.H * x.W
         nchunk = max(1, min(n // 32 if n >= 32 else 1, -(-512 // frames)))
         part = self.arena.get(frames * nchunk * heads * 657, torch.float32)

@@ -55,7 +55,18 @@ class CpuOps:
     def conv_workspace_bytes(self, d):
         return 0
 
-    def conv(self, d, x, in_bytes, wp, segs, bias, rowscale, residual, out, ws):
+    def conv_rms_ok(self, d) -> bool:
+        """mirror of mv2_conv_rms_ok for the emulation: staged-store shapes (the emulation has no split-K)"""
+        es = 2 if d['dtype'] == 0 else 4
+        return d['store'] != STORE_NCTHW_F32 and (d['out_c'] * es) % 16 == 0 and d['co'] % (16 // es) == 0
+
+    def conv_rms(self, d, x, in_bytes, wp, segs, bias, residual, out):
+        """mv2_conv_rms: rowscale = 1 / max(|gathered row|, 1e-12), taken over the rows the GEMM gathers"""
+        st = self.conv(d, x, in_bytes, wp, segs, bias, None, residual, out, None, rms_fused=True)
+        st.what = 'conv_rms'
+        return st
+
+    def conv(self, d, x, in_bytes, wp, segs, bias, rowscale, residual, out, ws, rms_fused=False):
         d = dict(d)
         acc = self.acc
 
@@ -78,6 +89,7 @@ class CpuOps:
             nsteps = d['nsteps']
             W = wp.to(acc)                         # (nsteps, co_pad, kel)
             D = torch.zeros(M, d['co_pad'], dtype=acc)
+            ss = torch.zeros(M, dtype=acc)
             sg = segs.reshape(-1, 2)
             chunk = max(1, (1 << 22) // max(1, seg_el))
             for s in range(nsteps):
@@ -105,6 +117,9 @@ class CpuOps:
                         assert int(idx.min()) >= 0
                         a = flat[idx] * okc[:, None].to(acc)
                         D[sl] += a @ wseg.t()
+                        ss[sl] += (a * a).sum(dim=1)
+            if rms_fused:
+                D = D * (1.0 / ss.sqrt().clamp(min=1e-12))[:, None]
             if rowscale is not None:
                 D = D * rowscale[:M].to(acc)[:, None]
             if bias is not None:
@@ -288,38 +303,6 @@ class CpuOps:
             self.se_pool(dt, out, se_wk, se_bk, se_part, frames, Pn, Cc, nchunk)(stream)
         step.outs = [out, se_part]
         step.what = 'pw_se'
-        return step
-
-    def ru_tail_rows(self, dt, rows, Pn, Cc, hidden) -> int:
-        """mirror of mv2_ru_tail_rows (rutail.hip): bf16, C in 128 / 256 / 512, hidden = C / 2, <= 256 records per frame"""
-        if dt != 0 or Cc not in (128, 256, 512) or rows % Pn or hidden != Cc // 2:
-            return 0
-        bp = 64 if (Pn % 64 == 0 and rows // 64 >= 512) else (32 if Pn % 32 == 0 else 0)
-        return bp if bp and Pn // bp <= 256 else 0
-
-    def ru_tail_sizes(self, rows, Pn, Cc, bp):
-        return (rows // bp) * (Cc + 4) * 4, (4 + rows // Pn) * 4
-
-    def ru_tail(self, dt, x, wp, bias, se_wk, se_bk, w1t16, b1, w2t16, b2, residual, out, rec, sync, rows, Pn, Cc, hidden):
-        """mv2_ru_tail: y = bf16(ELU(conv1(x) + b)); per frame softmax pooling of y, gate with the bf16 fc weights (fp accumulation),
-        out = bf16(gate * y + residual).  Mathematically the merge of the per-workgroup records the kernel exchanges."""
-        assert self.ru_tail_rows(dt, rows, Pn, Cc, hidden)
-        def step(stream):
-            w = self._plain_from_frag_major(wp).reshape(-1, wp.shape[1], wp.shape[2])
-            w2d = w.permute(1, 0, 2).reshape(wp.shape[1], -1)[:Cc, :Cc].to(self.acc)
-            y = x[: rows * Cc].reshape(rows, Cc).to(self.acc) @ w2d.t() + bias.to(self.acc)
-            y = torch.where(y > 0, y, torch.expm1(y.clamp(max=0)))
-            y = y.to(torch.bfloat16).to(self.acc)                               # the tile is kept in LDS as bf16
-            frames = rows // Pn
-            yr = y.reshape(frames, Pn, Cc)
-            a = torch.softmax(yr @ se_wk.to(self.acc) + se_bk, dim=1)
-            pooled = torch.einsum('fp,fpc->fc', a, yr)
-            h = torch.nn.functional.leaky_relu(pooled @ w1t16.to(self.acc) + b1.to(self.acc), 0.1)
-            g = torch.sigmoid(h @ w2t16.to(self.acc) + b2.to(self.acc))
-            o = yr * g[:, None, :] + residual[: rows * Cc].reshape(frames, Pn, Cc).to(self.acc)
-            out[: rows * Cc].copy_(o.reshape(-1).to(out.dtype))
-        step.outs = [out]
-        step.what = 'ru_tail'
         return step
 
     def se_pool(self, dt, y, wk, bk, part, frames, Pn, Cc, nchunk):

@@ -237,7 +237,8 @@ def test_bf16_drift_within_reference_yardstick(case):
     oracle: test_fp32_mode_vs_reference_golden).  End to end: ids <= 1.1 x and recon mean|d| <= 1.05 x the yardstick means.  Smooth
     halves: <= 1.05 x the yardstick AND <= 1.10 x the recorded HIP values (the regression gate proper)."""
     y = _yardstick()[case]
-    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in y['kw'].items()}
+    tup = lambda v: tuple(tup(e) for e in v) if isinstance(v, list) else v        # JSON lists back to the layer-spec tuples
+    kw = {k: (tup(v) if k == 'layers' else v) for k, v in y['kw'].items()}
     sd = init_state_dict(make_cfg(**kw), seed=y['weight_seed'], randomize_se=True)
     t32, t16 = hip_tokenizer(dict(kw, use_gan=False), sd, torch.float32), hip_tokenizer(dict(kw, use_gan=False), sd, torch.bfloat16)
     acc = dict(ids=[], recon=[], dec=[], pre=[])
@@ -407,62 +408,6 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     # compare the records through what they are used for: normalised pooled vectors
     assert torch.allclose(pg[:, 2:] / pg[:, 1:2], pc_[:, 2:] / pc_[:, 1:2], atol=5e-3, rtol=5e-3)
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
-
-
-@pytest.mark.parametrize('C,frames,P', [(128, 20, 4096), (128, 3, 96), (256, 20, 1024), (256, 2, 64), (512, 20, 256), (512, 5, 256), (512, 36, 1024),
-                                        (128, 1, 16384), (256, 40, 4096)])
-def test_ru_tail_kernel_vs_emulation(C, frames, P):
-    """mv2_ru_tail (conv1 + ELU + SqueezeExcite + residual in one launch, rutail.hip; workgroups of a frame meet inside the launch)
-    against the CPU emulation, launched five times back to back on the same counter block (every launch must leave it zero, as a
-    graph replay needs), while a second stream keeps the chip busy with copies (uneven load: the case in which a missing
-    release / acquire shows).  (256, 40, 4096) has 2560 workgroups: more than the chip holds at once, i.e. the hand-out of tiles at
-    workgroup start is what keeps the frame rendezvous free of deadlock."""
-    from magvit2_pytorch_amd import pack as PK
-    from magvit2_pytorch_amd.ops_hip import HipOps
-    ops, cpu = HipOps('cuda:0'), CpuOps()
-    g = torch.Generator().manual_seed(C + frames)
-    rows, hidden = frames * P, C // 2
-    x = (torch.randn(rows, C, generator=g) * 0.7).to(torch.bfloat16)
-    res = torch.randn(rows, C, generator=g).to(torch.bfloat16)
-    w = torch.randn(C, C, generator=g) / C ** 0.5
-    bias = torch.randn(C, generator=g) * 0.1
-    wk = torch.randn(C, generator=g) / C ** 0.5
-    w1t = (torch.randn(C, hidden, generator=g) / C ** 0.5).to(torch.bfloat16)
-    b1 = torch.randn(hidden, generator=g) * 0.1
-    w2t = (torch.randn(hidden, C, generator=g) / hidden ** 0.5).to(torch.bfloat16)
-    b2 = torch.randn(C, generator=g) * 0.5
-    pc = PK.pack_pointwise(w, bias, torch.bfloat16)
-    wp = PK.to_frag_major(pc.wp)
-    bp = ops.ru_tail_rows(PK.MV2_BF16, rows, P, C, hidden)
-    assert bp == cpu.ru_tail_rows(PK.MV2_BF16, rows, P, C, hidden) and bp in (32, 64)
-    assert ops.ru_tail_rows(PK.MV2_F32, rows, P, C, hidden) == 0 and ops.ru_tail_rows(PK.MV2_BF16, rows, P, C, hidden + 16) == 0
-    rec_bytes, sync_bytes = ops.ru_tail_sizes(rows, P, C, bp)
-    assert (rec_bytes, sync_bytes) == cpu.ru_tail_sizes(rows, P, C, bp)
-    out_c = torch.empty(rows * C, dtype=torch.bfloat16)
-    cpu.ru_tail(PK.MV2_BF16, x.reshape(-1), wp, pc.bias, wk, 0.25, w1t, b1, w2t, b2, res.reshape(-1), out_c, None, None, rows, P, C, hidden)(None)
-    dev = ops.device
-    d = lambda t: t.to(dev)
-    out_g = torch.empty(rows * C, dtype=torch.bfloat16, device=dev)
-    rec = torch.empty(rec_bytes // 4, device=dev)
-    sync = torch.zeros(sync_bytes // 4, dtype=torch.int32, device=dev)
-    step = ops.ru_tail(PK.MV2_BF16, d(x.reshape(-1)), d(wp), d(pc.bias), d(wk), 0.25, d(w1t), d(b1), d(w2t), d(b2), d(res.reshape(-1)), out_g, rec, sync,
-                       rows, P, C, hidden)
-    side = torch.cuda.Stream()
-    junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    b = out_c.float()
-    for rep in range(5):
-        out_g.zero_()
-        with torch.cuda.stream(side):
-            for _ in range(4):
-                junk.copy_(junk.flip(0))
-        step(ops.current_stream())
-        ops.synchronize()
-        assert int(sync.abs().sum()) == 0, f'launch {rep} left counters behind: {sync[:8].tolist()}'
-        a = out_g.cpu().float()
-        err = (a - b).abs()
-        assert (err <= 2 ** -6 * b.abs() + 4e-3).all(), (rep, err.max().item())
-        assert (a != b).float().mean() < 0.05
-    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------- conditioned layers (SURVEY.md §8 f2)
