@@ -26,8 +26,12 @@ Extra objects on the JSON line:
                    durations, each measured live with HIP events on the launch stream.  traffic: HBM-side bytes per launch
                    from the committed rocprofv3 PMC passes (`traffic_source` names the file; null when none applies).
   exact_fp32_mode— (N = 1, configs[1]) throughput and id mismatch of the bit-exact mode (fp32 storage + fp32 MFMA).
-  cpu_baseline   — the CPU oracle (oracle/restate.py, torch fp32) timed on this box's host cores on a bounded sample of the
-                   same workload (rank 0, N = 1 only), plus its bf16-autocast drift (the tolerance yardstick of the bf16 path).
+  cpu_baseline   — the CPU oracle (oracle/restate.py, torch fp32; kind "port": /root/reference does not exist on the GPU box) timed on this
+                   box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).  `cores` = the thread count of the
+                   timed runs, chosen by the printed thread sweep over {all, 1/2, 1/4, 32} of `cores_available`; plus its
+                   bf16-autocast drift (one draw of the tolerance yardstick; the six-seed yardstick of the tests comes from the
+                   real reference, tests/golden/bf16_yardstick.json).
+  roofline.encode_path — MFMA and HBM fractions of the encoder launches alone (the path north_star names), same event table.
 """
 from __future__ import annotations
 
@@ -80,6 +84,16 @@ def respawn_if_needed(args):
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def kernel_source_hash():
+    """sha256 over the conv3 kernel sources: what profiles/r03_traffic.json is stamped with (tools/pmc_aggregate.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ('conv3.hip', 'conv_common.h', 'common.h'):
+        with open(os.path.join(ROOT, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def per_launch_profile(tok, video, ops, tokenize_only=False):
@@ -208,18 +222,36 @@ def main():
     all_ms = sum(r['ms'] for r in rows)
     achieved = k3_flops / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
     all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # HBM-side bytes per conv3 launch: from the committed rocprofv3 --pmc passes of THIS command (not collectable in-process).  The file is
+    # stamped with a hash of the kernel sources it was measured on; a stale file is not printed.
     traffic, traffic_source = None, None
-    tf = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    tf = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
     if os.path.exists(tf) and args.dtype == 'bf16' and B == 1 and cfg_id == 1:
         try:
-            traffic = json.load(open(tf)).get('conv3_kernel_hbm_bytes_per_launch')
-            traffic_source = 'profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; not collectable in-process)'
+            js = json.load(open(tf))
+            if js.get('kernel_source_sha256') == kernel_source_hash():
+                traffic = js.get('conv3_kernel_hbm_bytes_per_launch')
+                traffic_source = 'profiles/r03_traffic.json (rocprofv3 --pmc passes of this command on these kernel sources: tools/gpu_profile.sh)'
+            else:
+                traffic_source = 'profiles/r03_traffic.json is stale (measured on other kernel sources): not printed'
         except Exception:
             traffic = None
+    # encode path alone (north_star names it): MFMA and HBM fractions from the same event table; algorithmic bytes per SURVEY.md §8(d)
+    enc_n = len(tok._plan(B, T)[0].enc_steps)
+    enc_rows = rows[:enc_n]
+    enc_ms, enc_flops = sum(r['ms'] for r in enc_rows), sum(r['flops'] for r in enc_rows)
+    enc_bytes = (365e6 * B + 119e6) if cfg_id in (1, 2) else None
+    encode_path = dict(launches=enc_n, ms=round(enc_ms, 4), flops=enc_flops,
+                       mfma_frac=round(enc_flops / (enc_ms * 1e-3) / 1e12 / peak, 4) if enc_ms > 0 else None,
+                       hbm_frac=round(enc_bytes / (enc_ms * 1e-3) / 6.3e12, 4) if (enc_bytes and enc_ms > 0) else None,
+                       algorithmic_bytes=enc_bytes, hbm_peak='6.3 TB/s achievable (8.0 spec)')
     roofline = dict(bound='mfma', kernel='conv3_kernel (ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
                     achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_source=traffic_source, launches=len(k3), flops_per_launch=k3_flops / max(len(k3), 1),
                     avg_launch_ms=round(k3_ms / max(len(k3), 1), 5),
+                    avg_launch_authority='profiles/r03_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
+                                         'the in-process figure issues every launch 5x back to back between two HIP events (L2/MALL-warm repeats)',
+                    encode_path=encode_path,
                     all_conv_launches=dict(launches=len(conv), flops_per_step=conv_flops, ms_per_step=round(conv_ms, 4),
                                            achieved=round(all_conv, 2), frac=round(all_conv / peak, 4)),
                     all_kernels_ms_per_step=round(all_ms, 4), graph_nodes=len(rows))
@@ -254,28 +286,40 @@ def main():
     if not args.no_cpu_baseline and world == 1 and not tokenize_only:
         from oracle.restate import OracleTokenizer
         try:
-            ncores = len(os.sched_getaffinity(0))
+            navail = len(os.sched_getaffinity(0))
         except AttributeError:
-            ncores = os.cpu_count() or 1
-        ncores = max(1, min(ncores, int(os.environ.get('MV2_CPU_BASELINE_THREADS', '64'))))
-        torch.set_num_threads(ncores)
-        log(f'cpu baseline: oracle on {ncores} threads (cpu_count={os.cpu_count()})')
+            navail = os.cpu_count() or 1
         orc = OracleTokenizer(sd, **cfg)
         vc = video[:1].cpu()
+        # thread sweep (one run each after a shared warm-up): torch's CPU convolutions stop scaling well before 256 threads, so "all
+        # cores" is measured, not assumed; the timed runs then use the fastest setting.  MV2_CPU_BASELINE_THREADS pins one setting.
+        pin = os.environ.get('MV2_CPU_BASELINE_THREADS')
+        cand = [int(pin)] if pin else sorted({navail, max(1, navail // 2), max(1, navail // 4), min(navail, 32)}, reverse=True)
+        torch.set_num_threads(cand[0])
         t1 = time.perf_counter()
         oc, orc_recon = orc(vc, return_codes=True, return_recon=True)                 # warm-up
-        ts = [time.perf_counter() - t1]
-        log(f'cpu baseline: warm-up {ts[0]:.2f} s')
-        budget = 20.0                                                              # bounded sample (seconds of CPU wall)
+        log(f'cpu baseline: warm-up {time.perf_counter() - t1:.2f} s on {cand[0]} threads (cores available: {navail})')
+        sweep = {}
+        for nt in cand:
+            torch.set_num_threads(nt)
+            t1 = time.perf_counter()
+            orc(vc, return_codes=True, return_recon=True)
+            sweep[nt] = round(time.perf_counter() - t1, 3)
+        ncores = min(sweep, key=sweep.get)
+        torch.set_num_threads(ncores)
+        log(f'cpu baseline: thread sweep (s/clip) {sweep} -> {ncores} threads')
+        ts = [sweep[ncores]]
+        budget = 20.0                                                              # bounded sample (seconds of CPU wall for the timed runs)
         while len(ts) < 4 and sum(ts) + ts[-1] < budget:
             t1 = time.perf_counter()
             oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
             ts.append(time.perf_counter() - t1)
-        timed = ts[1:] if len(ts) > 1 else ts
+        timed = ts
         med = sorted(timed)[len(timed) // 2]
         mism = (codes[:1].cpu() != oc).float().mean().item()
         derr = (recon[:1].cpu() - orc_recon).abs().mean().item()
-        cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=ncores, kind='port',
+        cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=ncores, cores_available=navail, kind='port',
+                            thread_sweep_s_per_clip={str(k): v for k, v in sweep.items()},
                             sample=f'1 clip (1,3,{T},128,128) fp32, {len(timed)} timed run(s) after warm-up, median {med:.2f} s/clip '
                                    f'(bounded to ~{budget:.0f} s of CPU time)',
                             ids_mismatch_vs_gpu=round(mism, 5), recon_mean_abs_diff_vs_gpu=round(derr, 6))

@@ -123,6 +123,17 @@ int mv2_conv_rms_ok(const mv2_conv_desc* desc);
 int mv2_conv_rms(const mv2_conv_desc* desc, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                  const float* bias, const void* residual, void* out, void* stream);
 
+/* mv2_conv_out — the decoder's output convolution (reference M:1127, 1642: CausalConv3d(dim -> channels, kt x 3 x 3), zero padding) as
+ * an HBM stream: bf16, Ci = 64, co <= 4, kt <= 3, stride 1, 'same' in space / causal in time, fp32 NCTHW store with `crop_t` leading
+ * frames dropped (MV2_STORE_NCTHW_F32).  `d` is the descriptor mv2_conv would take for the same layer (pt = kt - 1, ph = pw = 1,
+ * check_bounds = 1); mv2_conv_out_eligible() says whether it qualifies (else: mv2_conv).  A workgroup stages the kt halo frames of an
+ * 8 x 16 output tile in LDS once, instead of gathering every input row once per tap.
+ * wfrag: [kt * 9 taps (it, ih, iw row-major)][2 channel halves][64 lanes][8 bf16]: lane l holds W[co = l % 16][ci = 32 half + 8 (l / 16) + j]
+ * of the tap, zero for co >= d->co (the A operand of v_mfma_f32_16x16x32_bf16); mv2_conv_out_weight_bytes(kt) bytes. */
+int mv2_conv_out_eligible(const mv2_conv_desc* d);
+size_t mv2_conv_out_weight_bytes(int kt);
+int mv2_conv_out(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wfrag, const float* bias, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * mv2_conv3 — the ResidualUnit convolution: stride-1 kt x 3 x 3 (kt <= 3) causal-in-time / "same"-in-space
  * CausalConv3d over whole 128-byte channel chunks, C_out >= 64.

@@ -339,39 +339,25 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
-    // U tokens per trip: their 2 U row loads are in flight together (one token per trip is a chain of dependent L2 / HBM latencies:
-    // 40 trips took 30 us on MI355X for a 10 MB tensor); tokens are accumulated in order, so the sums keep their order
-    constexpr int U = 4, NC = 8 / E::kVec;
-    for (int tb = t0; tb < t1; tb += U) {
-        i32x4 kq[U][NC], vq[U][NC];
+    for (int t = t0; t < t1; ++t) {
+        const int64_t row = ((int64_t)f * n + t) * ld;
+        float k[8], v[9];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = min(tb + u, t1 - 1);                       // clamped duplicates are skipped below
-            const int64_t row = ((int64_t)f * n + t) * ld;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                kq[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
-                vq[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
-            }
+        for (int c = 0; c < 8 / E::kVec; ++c) {
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
         }
+        v[8] = 1.f;
+        float ki = k[0];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (tb + u >= t1) break;
-            float k[8], v[9];
+        for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kq[u][c], k + c * E::kVec); Chunk<E>::unpack(vq[u][c], v + c * E::kVec); }
-            v[8] = 1.f;
-            float ki = k[0];
+        for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
 #pragma unroll
-            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+        for (int jj = 0; jj < 8; ++jj) {
+            const float ph = (ki * k[jj]) * r2;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float ph = (ki * k[jj]) * r2;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
-            }
+            for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
         }
     }
     float* dst = part + (((int64_t)f * nchunk + j) * heads + h) * TAY_S;

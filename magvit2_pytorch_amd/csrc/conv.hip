@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         for (int i = 0; i < RP; ++i) { rowbase[i] = tab[2 * (r0 + 32 * i)]; rowmask[i] = tab[2 * (r0 + 32 * i) + 1]; }
         __syncthreads();
     }
+    // epilogue operands that only depend on the tile are requested now: their round trip hides under the K loop
+    static_assert(BPOS <= 256 && BCO <= 256, "one prefetched epilogue operand per thread");
+    const float bias_pf = (p.bias && tid < BCO && n0 + tid < d.co_pad) ? p.bias[n0 + tid] : 0.f;
+    const float rs_pf = (p.rowscale && tid < BPOS && m0 + tid < p.M) ? p.rowscale[m0 + tid] : 1.f;
     const int lg = p.lg_seg_chunks;
     const int seg_sub = c >> lg;
     const uint32_t seg_inner = (uint32_t)(c & ((1 << lg) - 1)) * 16u;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
                 if (c == 0) rs_lds[r0 + 32 * i] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
             }
         }
-        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; }, true, p.rms_fused != 0);
+        staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; }, true, p.rms_fused != 0, true, rs_pf, bias_pf);
         CV_PROF(2)
         CV_PROF_END
         return;

@@ -162,7 +162,8 @@ __device__ __forceinline__ bool stage_ok(const ConvParams& p) {
 // only help with the row stores of phase 2
 template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NT = 256, typename RowFn>
 __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, f32x16 (&acc)[WCO][WPOS], int n0, int wco,
-                                                int wpos, int tid, RowFn row_of, bool owner = true, bool rs_in_lds = false) {
+                                                int wpos, int tid, RowFn row_of, bool owner = true, bool rs_in_lds = false,
+                                                bool have_pf = false, float rs_pf = 1.f, float bias_pf = 0.f) {
     const mv2_conv_desc& d = p.d;
     typedef StageCfg<E, BCO, BPOS> SC;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -190,9 +191,12 @@ __device__ __forceinline__ void staged_epilogue(const ConvParams& p, char* lds, 
             }
         }
         rowtab[lp] = dr;
-        if (!rs_in_lds) rs_lds[lp] = (valid && p.rowscale) ? p.rowscale[m] : 1.f;     // rs_in_lds: the caller has put the scales there
+        // rs_in_lds: the caller has put the scales there.  have_pf: thread lp holds row lp's scale / column lp's bias, requested in the
+        // kernel PROLOGUE (BPOS, BCO <= NT): no dependent global round trip at the head of the epilogue.
+        if (!rs_in_lds) rs_lds[lp] = have_pf ? rs_pf : ((valid && p.rowscale) ? p.rowscale[m] : 1.f);
     }
-    for (int q = tid; q < BCO; q += NT) bias_lds[q] = (p.bias && n0 + q < d.co_pad) ? p.bias[n0 + q] : 0.f;
+    if (have_pf) { if (tid < BCO) bias_lds[tid] = bias_pf; }
+    else for (int q = tid; q < BCO; q += NT) bias_lds[q] = (p.bias && n0 + q < d.co_pad) ? p.bias[n0 + q] : 0.f;
     __syncthreads();
     // ---- phase 1: finish values per lane, write the tile
 #pragma unroll

@@ -252,22 +252,6 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
     float* slab = red + 32;           // 1024 partial sums
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pf = part + (int64_t)f * nchunk * (C + 2);
-    // The launch is a chain of dependent round trips (records -> pooled -> fc1 -> fc2: 7-14 us for a few hundred KB).  The two weight
-    // matrices do not depend on the records: every thread's first 16 fc1 and fc2 weights are requested before anything else.
-    constexpr int PF = 16;
-    float w1pf[PF], w2pf[PF];
-    {
-        const int KS = max(1, 1024 / hidden);
-        const int k = tid % hidden, cs = tid / hidden;
-        const int per = (C + KS - 1) / KS, c0 = cs * per, c1 = min(C, c0 + per);
-#pragma unroll
-        for (int u = 0; u < PF; ++u) w1pf[u] = (cs < KS && c0 + u < c1) ? w1t[(int64_t)(c0 + u) * hidden + k] : 0.f;
-        const int GS = max(1, 1024 / C);
-        const int c = tid % C, ks = tid / C;
-        const int perk = (hidden + GS - 1) / GS, k0 = ks * perk, k1 = min(hidden, k0 + perk);
-#pragma unroll
-        for (int u = 0; u < PF; ++u) w2pf[u] = (ks < GS && k0 + u < k1) ? w2t[(int64_t)(k0 + u) * C + c] : 0.f;
-    }
     float m = -INFINITY;
     for (int j = tid; j < nchunk; j += 1024) m = fmaxf(m, pf[(int64_t)j * (C + 2)]);
     m = wave_max(m);
@@ -321,12 +305,7 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
         if (cs < KS) {
             const int c0 = cs * per, c1 = min(C, c0 + per);
             float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int u = 0; u < PF; u += 2) {        // the prefetched weights (zeros past the slice)
-                a0 += w1pf[u] * ((c0 + u < c1) ? pooled[c0 + u] : 0.f);
-                a1 += w1pf[u + 1] * ((c0 + u + 1 < c1) ? pooled[c0 + u + 1] : 0.f);
-            }
-            int c = min(c1, c0 + PF);
+            int c = c0;
             for (; c + 16 <= c1; c += 16) {          // 16 independent loads in flight per thread
                 float w[16];
 #pragma unroll
@@ -358,12 +337,7 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
         if (ks < GS) {
             const int k0 = ks * per, k1 = min(hidden, k0 + per);
             float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int u = 0; u < PF; u += 2) {
-                a0 += w2pf[u] * ((k0 + u < k1) ? hid[k0 + u] : 0.f);
-                a1 += w2pf[u + 1] * ((k0 + u + 1 < k1) ? hid[k0 + u + 1] : 0.f);
-            }
-            int k = min(k1, k0 + PF);
+            int k = k0;
             for (; k + 16 <= k1; k += 16) {
                 float w[16];
 #pragma unroll
@@ -487,15 +461,6 @@ __global__ __launch_bounds__(1024) void se_rec_fc1_kernel(const float* __restric
     float* pooled = wr + R;             // C
     float* slab = pooled + C;           // 1024
     const float* pf = part + (int64_t)f * nchunk * (C + 2);
-    // The launch is a chain of memory round trips (5.8 us for a few KB of work): the fc1 weights of this thread do not depend on the
-    // records, so their first PF loads fly together with the record loads instead of after two barriers.
-    constexpr int PF = 32;
-    const int KS_ = 1024 / hs;
-    const int kl_ = tid % hs, cs_ = tid / hs, k_ = sl * hs + kl_;
-    const int per_ = (C + KS_ - 1) / KS_, c0_ = cs_ * per_, c1_ = min(C, c0_ + per_);
-    float wpf[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) wpf[u] = (k_ < hidden && c0_ + u < c1_) ? w1t[(int64_t)(c0_ + u) * hidden + k_] : 0.f;
 #pragma unroll 4
     for (int i = tid; i < R * (C + 2); i += 1024) sm[i] = pf[i];
     __syncthreads();
@@ -519,12 +484,6 @@ __global__ __launch_bounds__(1024) void se_rec_fc1_kernel(const float* __restric
     if (k < hidden) {
         const int c0 = cs * per, c1 = min(C, c0 + per);
         int c = c0;
-#pragma unroll
-        for (int u = 0; u < PF; u += 2) {                // the prefetched weights (zeros past the slice)
-            a0 += wpf[u] * ((c0 + u < c1) ? pooled[c0 + u] : 0.f);
-            a1 += wpf[u + 1] * ((c0 + u + 1 < c1) ? pooled[c0 + u + 1] : 0.f);
-        }
-        c = min(c1, c0 + PF);
         for (; c + 16 <= c1; c += 16) {
             float w[16];
 #pragma unroll
@@ -568,42 +527,15 @@ __global__ __launch_bounds__(1024) void se_fc2_apply_kernel(const void* __restri
     float* slab = hs + hidden;      // 1024
     float* g = slab + 1024;         // cw
     const int f = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < hidden; k += 1024) hs[k] = hidv[(int64_t)f * hidden + k];
+    __syncthreads();
     const int GS = 1024 / cw;
     const int cl = tid % cw, ks = tid / cw, c = sl * cw + cl;
     const int per = (hidden + GS - 1) / GS;
-    // Round trips that do not depend on each other are issued together at the top (the launch is a latency chain: 5.3 us for 5 MB):
-    // the thread's first 16 fc2 weights, and the y / residual chunks of its first two items, fly with the hidden vector.
-    constexpr int PF = 16, NI = 2;
-    const int cps = cw / KV;                         // 16-byte chunks of the slice per row (power of two)
-    const int lg = 31 - __clz(cps);
-    const int items = P << lg;
-    const int64_t row0 = (int64_t)f * P;
-    float wpf[PF];
-    {
-        const int k0 = ks * per, k1 = min(hidden, k0 + per);
-#pragma unroll
-        for (int u = 0; u < PF; ++u) wpf[u] = (k0 + u < k1) ? w2t[(int64_t)(k0 + u) * C + c] : 0.f;
-    }
-    i32x4 ypf[NI], rpf[NI];
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        const int i = tid + u * 1024;
-        const int ic = min(i, items - 1);
-        const int64_t idx = ((row0 + (ic >> lg)) * C + (int64_t)sl * cw) / KV + (ic & (cps - 1));
-        ypf[u] = ((const i32x4*)y)[idx];
-        rpf[u] = res ? ((const i32x4*)res)[idx] : ypf[u];
-    }
-    for (int k = tid; k < hidden; k += 1024) hs[k] = hidv[(int64_t)f * hidden + k];
-    __syncthreads();
     {
         const int k0 = ks * per, k1 = min(hidden, k0 + per);
         float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < PF; u += 2) {
-            a0 += wpf[u] * ((k0 + u < k1) ? hs[k0 + u] : 0.f);
-            a1 += wpf[u + 1] * ((k0 + u + 1 < k1) ? hs[k0 + u + 1] : 0.f);
-        }
-        int k = min(k1, k0 + PF);
+        int k = k0;
         for (; k + 16 <= k1; k += 16) {
             float w[16];
 #pragma unroll
@@ -621,21 +553,11 @@ __global__ __launch_bounds__(1024) void se_fc2_apply_kernel(const void* __restri
         g[tid] = 1.f / (1.f + expf(-a));
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {                   // the prefetched items
-        const int i = tid + u * 1024;
-        if (i < items) {
-            const int p = i >> lg, ch = i & (cps - 1);
-            const int64_t idx = ((row0 + p) * C + (int64_t)sl * cw) / KV + ch;
-            float a[8], r[8];
-            Chunk<E>::unpack(ypf[u], a);
-            Chunk<E>::unpack(rpf[u], r);
-#pragma unroll
-            for (int k = 0; k < KV; ++k) a[k] = a[k] * g[ch * KV + k] + (res ? r[k] : 0.f);
-            ((i32x4*)out)[idx] = Chunk<E>::pack(a);
-        }
-    }
-    for (int i = tid + NI * 1024; i < items; i += 1024) {
+    const int cps = cw / KV;                         // 16-byte chunks of the slice per row (power of two)
+    const int lg = 31 - __clz(cps);
+    const int items = P << lg;
+    const int64_t row0 = (int64_t)f * P;
+    for (int i = tid; i < items; i += 1024) {
         const int p = i >> lg, ch = i & (cps - 1);
         const int64_t idx = ((row0 + p) * C + (int64_t)sl * cw) / KV + ch;
         const i32x4 yv = ((const i32x4*)y)[idx];

@@ -31,10 +31,7 @@ template <int CT, int PT>
 __global__ __launch_bounds__(256) void pw_se_kernel(const PwSeParams p) {
     typedef PwSeLds<CT, PT> L;
     constexpr int C = L::C, BP = L::BP, PITCH = L::PITCH;
-    // k-steps of 16 channels; k-steps of weight fragments in flight.  The launch is a chain of memory round trips, not MFMA work (2.7 GF):
-    // at C = 512 one workgroup per CU streams 512 KB of weights, and with 4 k-steps in flight that was 8 dependent L2 round trips
-    // (12 us per launch on MI355X); 16 in flight (256 registers of a 512-register wave: one workgroup per CU anyway) makes it 2.
-    constexpr int KS = C / 16, D = CT == 4 ? 16 : 8;
+    constexpr int KS = C / 16, D = (CT * PT >= 8) ? 4 : 8;   // k-steps of 16 channels; k-steps of weight fragments in flight (L2 latency)
     constexpr int CPR = C / 8, NLD = BP * CPR / 256;     // 16-byte chunks per row; chunks per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;

@@ -173,6 +173,18 @@ def pack_conv3d(w, bias, dtype, frag_major=False):
     return pc
 
 
+def pack_conv_out(w):
+    """mv2_conv_out's weight image (include/mv2.h): w (co <= 4, 64, kt, 3, 3) -> [kt * 9 taps][2 halves][64 lanes][8] bf16 with
+    lane l = (co = l % 16, channel group l // 16): the A operand of v_mfma_f32_16x16x32_bf16, zero rows for co >= w.shape[0]."""
+    co, ci, kt, kh, kw = w.shape
+    assert ci == 64 and co <= 4 and kh == 3 and kw == 3 and 1 <= kt <= 3
+    wt = torch.zeros(16, 64, kt, 3, 3)
+    wt[:co] = w.float()
+    # [co][half][kg][j][tap] -> [tap][half][kg][co][j]
+    img = wt.reshape(16, 2, 4, 8, kt * 9).permute(4, 1, 2, 0, 3).contiguous()
+    return img.reshape(kt * 9 * 2, 64, 8).to(torch.bfloat16)
+
+
 def pack_pointwise(w2d, bias, dtype, in_scale: Optional[torch.Tensor] = None, k_pad: Optional[int] = None):
     """w2d: (Co, Ci).  in_scale: per-input-channel factor folded into the columns (RMSNorm gamma*sqrt(C)).
     k_pad: physical input row length when the producer padded its channels (GEGLU hidden)."""

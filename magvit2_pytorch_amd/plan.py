@@ -48,6 +48,9 @@ class PackedModel:
 
         put('conv_in', P.pack_conv_in(f('conv_in.conv.weight'), f('conv_in.conv.bias'), dtype, self.c_in_pad))
         put('conv_out', P.pack_conv3d(f('conv_out.conv.weight'), f('conv_out.conv.bias'), dtype))
+        wo = f('conv_out.conv.weight')
+        if dtype == torch.bfloat16 and wo.shape[1] == 64 and wo.shape[0] <= 4 and tuple(wo.shape[3:]) == (3, 3) and wo.shape[2] <= 3:
+            self.frag['conv_out'] = dev(P.pack_conv_out(wo))               # mv2_conv_out's fragment image (convout.hip)
         self.separate_first_frame = bool(cfg.get('separate_first_frame_encoding'))
         if self.separate_first_frame:      # SameConv2d pair = the same packers with one time tap (reference :1113-1120)
             put('conv_in_first_frame', P.pack_conv_in(f('conv_in_first_frame.weight')[:, :, None], f('conv_in_first_frame.bias'), dtype, self.c_in_pad))
@@ -749,7 +752,18 @@ class Plan:
                        crop_t=crop_t, out_t=out_t, out_c=4)
             self.arena.put(padded)
             return
-        self._conv(steps, 'conv_out', pm.convs['conv_out'], x, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
+        pc = pm.convs['conv_out']
+        d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1,
+                 pt=kt - 1, ph=kh // 2, pw=kw // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=1,
+                 act=P.ACT_NONE, store=P.STORE_NCTHW_F32, rt=1, rh=1, rw=1, crop_t=crop_t, out_c=4, splitk=0)
+        if 'conv_out' in pm.frag and self.ops.conv_out_eligible(d) and not os.environ.get('MV2_NO_CONV_OUT'):
+            # the HBM-stream form (convout.hip): the halo frames of a tile are staged once instead of being gathered once per tap
+            steps.append(self.ops.conv_out(d, x.t, x.t.numel() * x.t.element_size(), pm.frag['conv_out'], pc.bias, out_t))
+            steps[-1].label = 'conv_out'
+            self.step_flops[id(steps[-1])] = 2.0 * x.rows * pc.co_real * pc.k_real
+            self.step_names.append('conv_out')
+            return
+        self._conv(steps, 'conv_out', pc, x, pt=kt - 1, ph=kh // 2, pw=kw // 2, store=P.STORE_NCTHW_F32,
                    crop_t=crop_t, out_t=out_t, out_c=4)
 
     # ------------------------------------------------------------------ execution

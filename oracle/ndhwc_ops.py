@@ -55,10 +55,58 @@ class CpuOps:
     def conv_workspace_bytes(self, d):
         return 0
 
+    def conv_out_eligible(self, d) -> bool:
+        """mirror of mv2_conv_out_eligible (convout.hip)"""
+        return (d['dtype'] == 0 and d['Ci'] == 64 and 1 <= d['co'] <= 4 and d['kh'] == 3 and d['kw'] == 3 and 1 <= d['kt'] <= 3 and d['st'] == 1
+                and d['sh'] == 1 and d['sw'] == 1 and d['pt'] == d['kt'] - 1 and d['ph'] == 1 and d['pw'] == 1 and d['check_bounds'] == 1
+                and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['store'] == STORE_NCTHW_F32 and d['act'] == 0
+                and 0 <= d['crop_t'] < d['To'])
+
+    def conv_out(self, d, x, in_bytes, wfrag, bias, out):
+        """mv2_conv_out: the dense kernel is read back from the fragment image; zero padding in space, causal zeros in time"""
+        d = dict(d)
+        def step(stream):
+            B, T, H, W, co, kt = d['B'], d['Ti'], d['Hi'], d['Wi'], d['co'], d['kt']
+            # [tap][half][kg][co16][j] -> w[co][ci = 32 half + 8 kg + j][it][ih][iw]
+            w = wfrag.to(self.acc).reshape(kt * 9, 2, 4, 16, 8).permute(3, 1, 2, 4, 0).reshape(16, 64, kt, 3, 3)[:co]
+            xin = x[: B * T * H * W * 64].reshape(B, T, H, W, 64).permute(0, 4, 1, 2, 3).to(self.acc)
+            xin = torch.nn.functional.pad(xin, (1, 1, 1, 1, kt - 1, 0))
+            y = torch.nn.functional.conv3d(xin, w, None if bias is None else bias[:co].to(self.acc))
+            y = y[:, :, d['crop_t']:]
+            out.reshape(-1)[: y.numel()].copy_(y.reshape(-1).float())
+        step.outs = [out]
+        step.what = 'conv_out'
+        return step
+
     def conv_rms_ok(self, d) -> bool:
-        """mirror of mv2_conv_rms_ok for the emulation: staged-store shapes (the emulation has no split-K)"""
+        """mirror of mv2_conv_rms_ok (conv.hip): staged-store shapes whose launch plan keeps the reduction in one workgroup.  The
+        launch plan (pick_tile / plan_launch) is restated here so that the emulated plan has the launches of the HIP plan."""
         es = 2 if d['dtype'] == 0 else 4
-        return d['store'] != STORE_NCTHW_F32 and (d['out_c'] * es) % 16 == 0 and d['co'] % (16 // es) == 0
+        if d['store'] == STORE_NCTHW_F32 or (d['out_c'] * es) % 16 != 0 or d['co'] % (16 // es) != 0:
+            return False
+        M = d['B'] * d['To'] * d['Ho'] * d['Wo']
+        co, cus = d['co'], self.cus
+        blocks128 = -(-co // 128) * -(-M // 128)
+        small = co >= 64 and blocks128 < 2 * cus
+        if d['act'] == ACT_GEGLU:
+            bco, bpos = (64, 256) if co <= 64 else ((64, 128) if small else (128, 128))
+        elif small:
+            bco, bpos = 64, 64
+        elif co <= 32:
+            bco, bpos = 32, 256
+        elif co <= 64:
+            bco, bpos = 64, 256
+        else:
+            bco, bpos = 128, 128
+        blocks = -(-co // bco) * -(-M // bpos)
+        sk = d.get('splitk', 0)
+        if sk <= 0:
+            sk = 1
+            if blocks < cus and d['nsteps'] >= 16:
+                sk = max(1, min((2 * cus + blocks - 1) // blocks, d['nsteps'] // 8, 16))
+        sk = min(sk, d['nsteps'])
+        sps = -(-d['nsteps'] // sk)
+        return -(-d['nsteps'] // sps) == 1
 
     def conv_rms(self, d, x, in_bytes, wp, segs, bias, residual, out):
         """mv2_conv_rms: rowscale = 1 / max(|gathered row|, 1e-12), taken over the rows the GEMM gathers"""

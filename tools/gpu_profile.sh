@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU-box helper: bench lines (+ breakdowns), rocprofv3 kernel stats and PMC passes -> gpurun_out/<tag>_*
-# usage: tools/gpu_profile.sh <tag> [pmc|nopmc]
+# GPU-box helper: bench lines (+ per-launch tables), rocprofv3 kernel stats and PMC passes -> gpurun_out/<tag>_*, summaries -> profiles/
+# (copy them back from gpurun_out/ afterwards: profiles/ on the GPU box is not merged).  usage: tools/gpu_profile.sh <tag> [pmc|nopmc]
 TAG=${1:-rX}; PMC=${2:-nopmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-(timeout 400 python bench.py --breakdown $O/${TAG}_per_launch_events_b1.json 2>&1 | tail -12) > $O/${TAG}_bench_b1.log 2>&1
+(timeout 400 python bench.py --breakdown $O/${TAG}_per_launch_events_b1.json 2>&1 | tail -14) > $O/${TAG}_bench_b1.log 2>&1
 (timeout 300 python bench.py --config 2 --steps 100 --no-cpu-baseline --no-exact --breakdown $O/${TAG}_per_launch_events_b4.json 2>&1 | tail -3) > $O/${TAG}_bench_b4.log 2>&1
 (timeout 300 python bench.py --config 4 --steps 100 --no-cpu-baseline 2>&1 | tail -3) > $O/${TAG}_bench_cfg4_fsq.log 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -15,8 +15,12 @@ if [ "$PMC" = "pmc" ]; then
   (timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq -- $BENCH > $O/${TAG}_pmc_sq.log 2>&1)
   (timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- $BENCH > $O/${TAG}_pmc_fetch.log 2>&1)
   (timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- $BENCH > $O/${TAG}_pmc_write.log 2>&1)
+  mkdir -p $O/${TAG}_summaries
+  python $R/tools/pmc_aggregate.py $O $TAG $O/${TAG}_summaries > $O/${TAG}_pmc_aggregate.log 2>&1
 fi
 cd $R
+ST=$(find $O/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$ST" ] && cp $ST $O/${TAG}_rocprofv3_kernel_stats_bench_b1.csv
 find $O -name "*.db" -size +20M -delete 2>/dev/null
-for f in $O/${TAG}_bench_b1.log $O/${TAG}_bench_b4.log $O/${TAG}_bench_cfg4_fsq.log; do [ -f $f ] && tail -2 $f | cut -c1-400; done
-ls $O | grep "^${TAG}" | tail -20
+find $O/${TAG}_prof $O/${TAG}_pmc_sq $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
+for f in $O/${TAG}_bench_b1.log $O/${TAG}_bench_b4.log $O/${TAG}_bench_cfg4_fsq.log; do [ -f $f ] && tail -1 $f | cut -c1-400; done
+ls $O | grep "^${TAG}" | tail -24

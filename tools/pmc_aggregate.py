@@ -54,7 +54,14 @@ def main(src, tag, dst):
             ws += per[k]['WRITE_SIZE'][0]; nw += launches[k].get('pmc_write', 0)
     if nf and nw:
         fetch_kb, write_kb = fs / nf, ws / nw
+        import hashlib
+        h = hashlib.sha256()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for fn in ('conv3.hip', 'conv_common.h', 'common.h'):                      # bench.py::kernel_source_hash
+            with open(os.path.join(root, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
+                h.update(f.read())
         js = dict(conv3_kernel_hbm_bytes_per_launch=int((2 * fetch_kb + write_kb) * 1024), launches_averaged=nf,
+                  kernel_source_sha256=h.hexdigest(),
                   fetch_size_kb_avg=round(fetch_kb, 1), write_size_kb_avg=round(write_kb, 1),
                   note='rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 3 --no-graph` (B=1, bf16), averaged over all conv3_kernel '
                        'launches (22 per forward); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a 16 B/lane coalesced '
