@@ -85,11 +85,30 @@ __device__ __forceinline__ TileInfo decode_unit(const ConvParams& p, uint32_t x,
     return ti;
 }
 
-// worker that owns linear group x when W workers split G groups as start(w) = floor(w G / W)
-__device__ __forceinline__ uint32_t worker_of(uint32_t x, uint32_t W, uint32_t G) {
-    return (uint32_t)((((uint64_t)x + 1) * W - 1) / G);
+// Range starts.  skew = 0: W workers split G units equally, start(w) = floor(w G / W).
+// skew > 0 (two workgroups per CU, W a multiple of 16): the two workgroups of a CU are (blockIdx, blockIdx + W / 2); the issue arbiter
+// favours the OLDER one (priority, then age), which therefore runs at its solo rate and finishes early, while the younger one does a
+// large part of its taps alone afterwards at the same solo rate (measured: 87k against 121k clocks for equal ranges at C = 512, the
+// launch lasts as long as the younger).  Ranges proportional to the two rates make the pair finish together: the older workgroup of
+// every pair takes (1000 + skew) / 2000 of the pair's units.  In worker order (after the XCD remap) the older workgroups are the
+// first half of each XCD's segment of W / 8 workers.
+__device__ __forceinline__ uint32_t start_of(uint32_t w, uint32_t W, uint32_t G, uint32_t skew) {
+    if (skew == 0) return (uint32_t)((uint64_t)w * G / W);
+    const uint32_t q = W >> 3, h = q >> 1;
+    const uint32_t seg = w / q, j = w - seg * q;
+    const uint64_t cw = (uint64_t)seg * q * 1000u + (j <= h ? (uint64_t)j * (1000u + skew) : (uint64_t)h * (1000u + skew) + (uint64_t)(j - h) * (1000u - skew));
+    return (uint32_t)(cw * G / ((uint64_t)W * 1000u));
 }
-__device__ __forceinline__ uint32_t start_of(uint32_t w, uint32_t W, uint32_t G) { return (uint32_t)((uint64_t)w * G / W); }
+// worker that owns linear unit x: the w with start(w) <= x < start(w + 1)
+__device__ __forceinline__ uint32_t worker_of(uint32_t x, uint32_t W, uint32_t G, uint32_t skew) {
+    if (skew == 0) return (uint32_t)((((uint64_t)x + 1) * W - 1) / G);
+    uint32_t lo = 0, hi = W - 1;                      // start(lo) <= x always; find the last w with start(w) <= x
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (start_of(mid, W, G, skew) <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 
 // ---- geometry (one tile class: 64 output channels x 8x16 positions, four waves, two workgroups per CU)
 constexpr int BCO = 64, TH = 8, TW = 16, BPOS = TH * TW;
@@ -162,6 +181,9 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 // each), LDS writes over taps 5-7.  The table lives behind the two halo images inside the reduce region (free while taps run).
 #ifndef MV2_C3_HTAB
 #define MV2_C3_HTAB 0
+#endif
+#ifndef MV2_C3_SKEW_DEFAULT
+#define MV2_C3_SKEW_DEFAULT 0
 #endif
 #ifndef MV2_C3_PSETS
 #define MV2_C3_PSETS 3
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
     // traffic, no ticket, no partial reduce, at the price of up to half a tile of imbalance per range end.  Measured (k3_bench,
     // profiles/r02_k3_align.log): batch 4 C = 64 / 128 / 256 350 / 291 / 276 -> 319 / 273 / 247 us; batch 1 C = 64 94 -> 83 us.
     auto range_start = [&](uint32_t w) -> uint32_t {
-        const uint32_t x = start_of(w, NW, G);
+        const uint32_t x = start_of(w, NW, G, (uint32_t)p.skew);
         if (!p.aligned || x >= G) return x;
         uint32_t gv;
         const TileInfo t = decode_unit(p, x, gv);
@@ -674,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket
             __syncthreads();
-            const uint32_t w_first = worker_of(ti.G0 + p.delta, NW, G), w_last = worker_of(ti.G0 + p.delta + ti.ng - 1, NW, G);
+            const uint32_t w_first = worker_of(ti.G0 + p.delta, NW, G, (uint32_t)p.skew), w_last = worker_of(ti.G0 + p.delta + ti.ng - 1, NW, G, (uint32_t)p.skew);
             const uint32_t nparts = w_last - w_first + 1;
             uint32_t* flag = (uint32_t*)(smem + L::kFlag);
             if (wave == 0 && lane_o == 0) {
@@ -686,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             __syncthreads();
             finish = *flag != 0;
             if (finish) {
-                const uint32_t s_first = start_of(w_first, NW, G);
+                const uint32_t s_first = start_of(w_first, NW, G, (uint32_t)p.skew);
 #pragma unroll
                 for (int a = 0; a < WCO; ++a)
 #pragma unroll
@@ -854,6 +876,7 @@ struct Plan3 {
     uint32_t delta;
     int workers;
     int aligned;               // worker ranges snapped to tile starts (no cut tiles)
+    int skew;                  // per mille of extra work for the older workgroup of a CU's pair (start_of)
     size_t slab_bytes;
 };
 
@@ -904,6 +927,13 @@ inline Plan3 plan3(const mv2_conv_desc& d) {
     P.aligned = P.n_tiles >= (int64_t)4 * P.workers ? 1 : 0;
 #ifdef MV2_EXPERIMENTS
     if (const char* e = getenv("MV2_C3_ALIGN")) P.aligned = atoi(e) != 0;
+#endif
+    // unequal ranges inside a CU's pair of workgroups (see start_of): only where there IS a pair (two workgroups per CU, worker count a
+    // multiple of 16 so that the XCD segments split into an older and a younger half)
+    P.skew = 0;
+    if (P.workers == 2 * cus && (P.workers & 15) == 0) P.skew = MV2_C3_SKEW_DEFAULT;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3_SKEW")) P.skew = (P.workers == 2 * cus && (P.workers & 15) == 0) ? atoi(e) : 0;
 #endif
     // two slab slots per worker (a worker's range cuts at most its first and its last tile)
     P.slab_bytes = P.workers > 1 ? (size_t)2 * P.workers * SLAB_BYTES : 0;
@@ -981,6 +1011,7 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
     p.splitk = 1; p.tiles_h = P.tiles_h; p.tiles_w = P.tiles_w; p.nchunk = P.nchunk; p.chunks_per_split = P.nchunk;
     p.counters = counters; p.gtot = (uint32_t)P.units; p.delta = P.delta; p.ws_bytes = (uint32_t)P.slab_bytes;
     p.aligned = P.aligned;
+    p.skew = P.skew;
     hipStream_t st = (hipStream_t)stream;
     if (wp2) return launch3<BF16, true>(p, P.workers, st);
     return d->dtype == MV2_BF16 ? launch3<BF16, false>(p, P.workers, st) : launch3<F32, false>(p, P.workers, st);

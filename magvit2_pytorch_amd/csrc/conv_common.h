@@ -44,6 +44,8 @@ struct ConvParams {
     // mv2_conv_rms: the per-row scale 1 / |gathered row| (RMSNorm, reference M:258-276) is computed inside the GEMM launch from the rows
     // it stages anyway; `rowscale` is null
     int32_t rms_fused;
+    // conv3.hip: per mille of extra work for the OLDER workgroup of a CU's pair (0 = equal ranges)
+    int32_t skew;
 };
 
 
