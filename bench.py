@@ -215,7 +215,7 @@ def main():
     rows = per_launch_profile(tok, video, ops, tokenize_only)
     log('per-launch event profile done')
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
-    conv = [r for r in rows if r['what'] in ('mv2_conv', 'mv2_conv3')]
+    conv = [r for r in rows if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_out', 'mv2_conv3')]
     k3 = [r for r in rows if r['what'] == 'mv2_conv3']      # incl. the fused '.k3+k1' launches (their FLOPs include the 1x1x1)
     conv_ms, conv_flops = sum(r['ms'] for r in conv), sum(r['flops'] for r in conv)
     k3_ms, k3_flops = sum(r['ms'] for r in k3), sum(r['flops'] for r in k3)
@@ -259,7 +259,7 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
         agg = {}
         for r in rows:
-            a = agg.setdefault(r['label'] if r['what'] in ('mv2_conv', 'mv2_conv3') else r['what'], dict(ms=0.0, flops=0.0, n=0))
+            a = agg.setdefault(r['label'] if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_out', 'mv2_conv3') else r['what'], dict(ms=0.0, flops=0.0, n=0))
             a['ms'] += r['ms']; a['flops'] += r['flops']; a['n'] += 1
         json.dump(dict(rows=rows, by_label=agg), open(args.breakdown, 'w'), indent=1)
 

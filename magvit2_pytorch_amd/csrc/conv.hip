@@ -32,8 +32,9 @@ extern "C" int mv2_conv_set_profile(void* device_buffer) {
 #endif
 
 // ------------------------------------------------------------------------------- main kernel
-template <typename E, int BCO, int BPOS, int WCO, int WPOS>
+template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NSET>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
+    static_assert(NSET == 2 || NSET == 4, "register sets of the load pipeline (even: LDS buffer = set parity)");
     constexpr int NWPOS = BPOS / (32 * WPOS);
     static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
     constexpr int RW = BCO / 32;    // weight rows staged per thread
@@ -139,10 +140,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // Two register sets (selected statically by step parity): the loads of step s+2 are issued while
-    // step s computes and step s+1 (issued one step earlier) is written to the other LDS buffer, so every
-    // gather has two steps of flight time before it is waited for.
-    i32x4 gw[2][RW], gp[2][RP];
+    // NSET register sets, two LDS buffers (both selected statically): while step s computes out of LDS buffer s % 2, step s + 1 (in
+    // flight since NSET steps) is written to the other buffer and the loads of step s + NSET are issued into the set step s has just
+    // left, so every gather has NSET steps of flight time before it is waited for.  NSET = 4 on the small tiles: their launches are
+    // 2-8 K steps long, i.e. with two sets a chain of 2-4 dependent memory round trips (6 us for 1.3 GF); with four, every load of
+    // a <= 4-step launch is in flight before the first wait.
+    i32x4 gw[NSET][RW], gp[NSET][RP];
     float rss[RP];                  // rms_fused: this thread's share (one 16-byte chunk per step) of the sum of squares of its RP rows
 #pragma unroll
     for (int i = 0; i < RP; ++i) rss[i] = 0.f;
@@ -166,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         for (int i = 0; i < RW; ++i)
             gw[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wo_ + (uint32_t)i * 32u * 128u), 0, 0);
     };
-    auto write_lds = [&](auto par_c) {
+    auto write_lds = [&](auto par_c) {                 // register set PAR -> LDS buffer PAR % 2
         constexpr int PAR = decltype(par_c)::value;
-        char* base = smem + PAR * STAGE;
+        char* base = smem + (PAR & 1) * STAGE;
 #pragma unroll
         for (int i = 0; i < RW; ++i) *(i32x4*)(base + lds_wr + i * 32 * 128) = gw[PAR][i];
 #pragma unroll
@@ -188,20 +191,23 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         // parity is relative to s_begin: step s_begin uses set / buffer 0
         // vmcnt retires IN ORDER: a descriptor fetched after a batch of gathers cannot be consumed before that
         // batch has landed.  So every descriptor is fetched BEFORE the gathers issued in the same step.
-        const mv2_seg sg0 = load_seg(s_begin), sg1 = load_seg(s_begin + 1);
-        mv2_seg sg = load_seg(s_begin + 2);
-        issue_loads(s_begin, sg0, IC<0>{});
-        issue_loads(s_begin + 1, sg1, IC<1>{});
+        mv2_seg sgp[NSET];
+#pragma unroll
+        for (int k = 0; k < NSET; ++k) sgp[k] = load_seg(s_begin + k);
+        mv2_seg sg = load_seg(s_begin + NSET);
+        issue_loads(s_begin, sgp[0], IC<0>{});
+        issue_loads(s_begin + 1, sgp[1], IC<1>{});
+        if constexpr (NSET == 4) { issue_loads(s_begin + 2, sgp[2], IC<2>{}); issue_loads(s_begin + 3, sgp[3], IC<3>{}); }
         write_lds(IC<0>{});
         __syncthreads();
         CV_PROF(0)
         auto step = [&](int s, auto par_c) {
             constexpr int PAR = decltype(par_c)::value;
-            const mv2_seg nxt = load_seg(s + 3);
-            issue_loads(s + 2, sg, IC<PAR>{});
+            const mv2_seg nxt = load_seg(s + NSET + 1);
+            issue_loads(s + NSET, sg, IC<PAR>{});          // set PAR held step s, which is in LDS since the previous step
             sg = nxt;
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch at the top of the step (the scheduler would sink it)
-            const char* base = smem + PAR * STAGE;
+            const char* base = smem + (PAR & 1) * STAGE;
             // fragment reads software-pipelined over two register sets
             i32x4 fw[2][WCO], fp[2][WPOS];
             auto read_frags = [&](int ks, auto set_c) {
@@ -230,15 +236,27 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             mma_frags(IC<0>{});
             mma_frags(IC<1>{});
-            write_lds(IC<PAR ^ 1>{});       // unconditional: after the last step it stores the zero dummy
+            write_lds(IC<(PAR + 1) % NSET>{});       // unconditional: after the last step it stores the zero dummy
             __syncthreads();
         };
         int s = s_begin;
-        for (; s + 1 < s_end; s += 2) {
-            step(s, IC<0>{});
-            step(s + 1, IC<1>{});
+        if constexpr (NSET == 2) {
+            for (; s + 1 < s_end; s += 2) {
+                step(s, IC<0>{});
+                step(s + 1, IC<1>{});
+            }
+            if (s < s_end) step(s, IC<0>{});
+        } else {
+            for (; s + 3 < s_end; s += 4) {
+                step(s, IC<0>{});
+                step(s + 1, IC<1>{});
+                step(s + 2, IC<2>{});
+                step(s + 3, IC<3>{});
+            }
+            if (s < s_end) step(s, IC<0>{});
+            if (s + 1 < s_end) step(s + 1, IC<1>{});
+            if (s + 2 < s_end) step(s + 2, IC<2>{});
         }
-        if (s < s_end) step(s, IC<0>{});
     }
     CV_PROF(1)
 
@@ -437,18 +455,18 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     return L;
 }
 
-template <typename E, int BCO, int BPOS, int WCO, int WPOS>
+template <typename E, int BCO, int BPOS, int WCO, int WPOS, int NSET>
 int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
     constexpr size_t lds_main = 2 * (size_t)(BCO + BPOS) * 128;
     constexpr size_t lds_epi = (size_t)StageCfg<E, BCO, BPOS>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     if (lds > 64 * 1024) {   // per-device attribute: set on every call rather than cached in a process-wide flag
-        hipError_t e = hipFuncSetAttribute((const void*)conv_kernel<E, BCO, BPOS, WCO, WPOS>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_kernel<E, BCO, BPOS, WCO, WPOS, NSET>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((unsigned)(L.n_co_tiles * L.n_pos_tiles), (unsigned)L.splitk);
-    hipLaunchKernelGGL((conv_kernel<E, BCO, BPOS, WCO, WPOS>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_kernel<E, BCO, BPOS, WCO, WPOS, NSET>), grid, dim3(256), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -456,11 +474,11 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
-    if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1>(p, L, st);
-    else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1>(p, L, st);
-    else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2>(p, L, st);
-    else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2>(p, L, st);
-    else rc = launch_cfg<E, 32, 256, 1, 2>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1, 4>(p, L, st);
+    else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1, 4>(p, L, st);
+    else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2, 2>(p, L, st);
+    else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2, 2>(p, L, st);
+    else rc = launch_cfg<E, 32, 256, 1, 2, 2>(p, L, st);
     if (rc != MV2_OK) return rc;
     if (L.splitk > 1) {
         const int groups = p.d.act == MV2_ACT_GEGLU ? p.d.co / 8 : (p.d.co + 3) / 4;

@@ -180,7 +180,7 @@ constexpr int SLAB_BYTES = BCO * BPOS * 4;
 // 1: table reads at the top of tap 0, the six loads between the two MFMA batches of tap 0.  2: loads spread over taps 0-2 (two rows
 // each), LDS writes over taps 5-7.  The table lives behind the two halo images inside the reduce region (free while taps run).
 #ifndef MV2_C3_HTAB
-#define MV2_C3_HTAB 0
+#define MV2_C3_HTAB 1      // measured r03g (tools/k3_bench levels): 84.1 / 77.7 / 72.0 / 71.5 / 41.5 / 26.5 -> 83.4 / 75.5 / 71.3 / 70.0 / 40.3 / 24.7 us
 #endif
 #ifndef MV2_C3_SKEW_DEFAULT
 #define MV2_C3_SKEW_DEFAULT 0
@@ -535,10 +535,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
                 if constexpr (TP < 3) read_htab(IC<2 * TP>{}, IC<2 * TP + 2>{});
 #endif
             } else {
-                if constexpr (TP == 0) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH>{});
+                // ABL 5 / 6 / 7 (experiments, TIMING ONLY): 5 = the next group's halo is never requested (the stale registers are still
+                // written), 6 = nor written to LDS, 7 = and the per-group barrier is dropped, 8 = 4 + 7 (bare MFMA stream): which part sets the solo rate
+                if constexpr (TP == 0 && MV2_C3_ABL < 5) issue_halo(S, S.nxt_chunk, S.nxt_it, IC<0>{}, IC<NH>{});
             }
-            if constexpr (TP == 8) __syncthreads();       // the next group's image is complete; this one has no reader left
-            if constexpr (MV2_C3_ABL == 3 || MV2_C3_ABL == 4) {
+            if constexpr (TP == 8 && MV2_C3_ABL != 7 && MV2_C3_ABL != 8) __syncthreads();       // the next group's image is complete; this one has no reader left
+            if constexpr (MV2_C3_ABL == 3 || MV2_C3_ABL == 4 || MV2_C3_ABL == 8) {
 #pragma unroll
                 for (int bb = 0; bb < WPOS; ++bb) { pset[NSET][bb] = pset[SET][bb]; asm volatile("" : "+v"(pset[NSET][bb])); }
             } else if constexpr (TP < 8) read_p(img, TP + 1, IC<NSET>{});
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
 #pragma unroll
                 for (int bb = 0; bb < WPOS; ++bb) TapMma<E>::run(wring[SLOT], pset[SET][bb], acc[A][bb]);
                 const uint32_t so = G < 9 * WCO ? S.cur_wb + (uint32_t)(G / WCO) * tapstride : S.nxt_wb + (uint32_t)((G - 9 * WCO) / WCO) * tapstride;
-                if constexpr (!(MV2_C3_ABL == 2 || MV2_C3_ABL == 4 || (MV2_C3_ABL == 1 && A == 1))) issue_w1(S, so, G % WCO, wring[SLOT]);
+                if constexpr (!(MV2_C3_ABL == 2 || MV2_C3_ABL == 4 || MV2_C3_ABL == 8 || (MV2_C3_ABL == 1 && A == 1))) issue_w1(S, so, G % WCO, wring[SLOT]);
                 else asm volatile("" : "+v"(wring[SLOT]));       // keep the slot live and opaque
             };
             static_assert(WCO == 2, "two channel tiles per wave");
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ConvParams p) {
             if constexpr (MV2_C3_HTAB == 2 && !MV2_C3_HSPLIT) {
                 if constexpr (TP >= HWT && TP < HWT + 3) write_halo(smem + other, IC<2 * (TP - HWT)>{}, IC<2 * (TP - HWT) + 2>{});
             } else
-            if constexpr (!MV2_C3_HSPLIT && TP == HWT) write_halo(smem + other, IC<0>{}, IC<NH>{});   // image of group gi-1: its last reader passed the previous barrier
+            if constexpr (!MV2_C3_HSPLIT && TP == HWT && MV2_C3_ABL < 6) write_halo(smem + other, IC<0>{}, IC<NH>{});   // image of group gi-1: its last reader passed the previous barrier
             if constexpr (PSETS == 2 && TP == 8) {      // the next group's tap 0 reads set 0
 #pragma unroll
                 for (int bb = 0; bb < WPOS; ++bb) pset[0][bb] = pset[1][bb];

@@ -593,7 +593,7 @@ class Plan:
         q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
         kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
         frames, n = x.B * x.T, x.H * x.W
-        nchunk = max(1, min(n // 32 if n >= 32 else 1, -(-512 // frames)))
+        nchunk = max(1, min(n // 32 if n >= 32 else 1, -(-int(os.environ.get('MV2_TAYLOR_BLOCKS', '512')) // frames)))
         part = self.arena.get(frames * nchunk * heads * 657, torch.float32)
         kvsum = self.arena.get(frames * heads * 657, torch.float32)
         o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)

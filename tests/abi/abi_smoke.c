@@ -36,6 +36,17 @@ int main(void) {
     if (mv2_conv3(&d, NULL, 0, NULL, NULL, NULL, NULL, 0, NULL, 0.f, NULL, NULL, NULL, 0, NULL, 0, NULL) == MV2_OK) return 10;
     if (mv2_lfq_stats_workspace_bytes(10, 13, 1) != 0) return 11;
     if (mv2_pw_se_rows(MV2_BF16, 81920, 4096, 128) != 64 || mv2_pw_se_rows(MV2_F32, 81920, 4096, 128) != 0) return 12;
+    /* the decoder's output convolution: eligibility is a pure function of the descriptor; its weight image is kt * 18 k-steps of 1 KB */
+    {
+        mv2_conv_desc o = d;
+        o.dtype = MV2_BF16; o.Ci = 64; o.co = 3; o.kt = 3; o.kh = 3; o.kw = 3; o.st = o.sh = o.sw = 1; o.pt = 2; o.ph = o.pw = 1; o.check_bounds = 1;
+        o.To = o.Ti; o.Ho = o.Hi; o.Wo = o.Wi; o.store = MV2_STORE_NCTHW_F32; o.act = MV2_ACT_NONE; o.crop_t = 0;
+        if (!mv2_conv_out_eligible(&o)) return 13;
+        o.Ci = 128;
+        if (mv2_conv_out_eligible(&o)) return 14;
+        if (mv2_conv_out_weight_bytes(3) != 54 * 1024 || mv2_conv_out_weight_bytes(4) != 0) return 15;
+        if (mv2_conv_out(&o, NULL, 0, NULL, NULL, NULL, NULL) == MV2_OK) return 16;
+    }
     free(w); free(a); free(b);
     printf("abi smoke ok (%zu byte image, %d strips)\n", bytes, strips);
     return 0;
