@@ -324,63 +324,53 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
 #define TAY_F 73
 #define TAY_S (73 * 9)
 
-// Two threads per (head, k-dim i): each owns half of the nine state columns (e = 0..4 / 5..8).  With one thread per (head, i) a block
-// was two waves of 90 accumulators each: 1040 waves on 1024 SIMDs, i.e. one instruction stream per SIMD with nothing to hide its
-// latencies behind (31 us for a 10 MB tensor).  Sums per state element keep their token order: results are bitwise those of the
-// one-thread form.
 template <typename E>
-__global__ __launch_bounds__(512) void taylor_kv_kernel(const void* __restrict__ kv, float* __restrict__ part, int n, int heads,
+__global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__ kv, float* __restrict__ part, int n, int heads,
                                                         int nchunk) {
     const int f = blockIdx.y, j = blockIdx.x;
-    const int h = threadIdx.x >> 4, i = (threadIdx.x >> 1) & 7, half = threadIdx.x & 1;
+    const int h = threadIdx.x >> 3, i = threadIdx.x & 7;
     if (h >= heads) return;
-    const int e0 = half ? 5 : 0;                          // first column of this thread; NE = 5 columns (the ninth of half 1 is a dummy)
-    constexpr int NE = 5;
     const int per = (n + nchunk - 1) / nchunk;
     const int t0 = j * per, t1 = min(n, t0 + per);
     const int ld = 2 * heads * 8;
-    float a2[8][NE], a1[NE], a0[NE];
+    float a2[8][9], a1[9], a0[9];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { a1[e] = 0.f; a0[e] = 0.f;
+    for (int e = 0; e < 9; ++e) { a1[e] = 0.f; a0[e] = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
     for (int t = t0; t < t1; ++t) {
         const int64_t row = ((int64_t)f * n + t) * ld;
-        float k[8], v[10];
+        float k[8], v[9];
 #pragma unroll
         for (int c = 0; c < 8 / E::kVec; ++c) {
             Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
             Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
         }
-        v[8] = 1.f; v[9] = 0.f;
-        float ve[NE];
-#pragma unroll
-        for (int e = 0; e < NE; ++e) ve[e] = half ? v[5 + e] : v[e];
+        v[8] = 1.f;
         float ki = k[0];
 #pragma unroll
         for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) { a0[e] += ve[e]; a1[e] += ki * ve[e]; }
+        for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const float ph = (ki * k[jj]) * r2;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) a2[jj][e] += ph * ve[e];
+            for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
         }
     }
     float* dst = part + (((int64_t)f * nchunk + j) * heads + h) * TAY_S;
-    const int ne = half ? 4 : 5;                          // real columns of this thread
     if (i == 0) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) if (e < ne) dst[e0 + e] = a0[e];
+        for (int e = 0; e < 9; ++e) dst[e] = a0[e];
     }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) if (e < ne) dst[(1 + i) * 9 + e0 + e] = a1[e];
+    for (int e = 0; e < 9; ++e) dst[(1 + i) * 9 + e] = a1[e];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
-        for (int e = 0; e < NE; ++e) if (e < ne) dst[(9 + 8 * i + jj) * 9 + e0 + e] = a2[jj][e];
+        for (int e = 0; e < 9; ++e) dst[(9 + 8 * i + jj) * 9 + e] = a2[jj][e];
 }
 
 __global__ __launch_bounds__(256) void taylor_reduce_kernel(const float* __restrict__ part, float* __restrict__ kvsum, int heads,
@@ -497,7 +487,7 @@ extern "C" int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames,
     if (!kv || !part || frames <= 0 || n <= 0 || heads <= 0 || heads > 32 || nchunk <= 0 || nchunk > n) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
     dim3 grid((unsigned)nchunk, (unsigned)frames);
-    const unsigned threads = (unsigned)(heads * 16);
+    const unsigned threads = (unsigned)(heads * 8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_kernel<BF16>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);
     else hipLaunchKernelGGL((taylor_kv_kernel<F32>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);

@@ -142,9 +142,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 
     // NSET register sets, two LDS buffers (both selected statically): while step s computes out of LDS buffer s % 2, step s + 1 (in
     // flight since NSET steps) is written to the other buffer and the loads of step s + NSET are issued into the set step s has just
-    // left, so every gather has NSET steps of flight time before it is waited for.  NSET = 4 on the small tiles: their launches are
-    // 2-8 K steps long, i.e. with two sets a chain of 2-4 dependent memory round trips (6 us for 1.3 GF); with four, every load of
-    // a <= 4-step launch is in flight before the first wait.
+    // left, so every gather has NSET steps of flight time before it is waited for.  NSET = 4 was measured on the small tiles (r03h:
+    // every load of a <= 4-step launch in flight before the first wait) and is NOT faster (qkv 13.8 -> 15.8 us, out 8.9 -> 9.6,
+    // kv 13.2 -> 14.7: the launches are not bound by the depth of this pipeline); every instantiation uses 2.
     i32x4 gw[NSET][RW], gp[NSET][RP];
     float rss[RP];                  // rms_fused: this thread's share (one 16-byte chunk per step) of the sum of squares of its RP rows
 #pragma unroll
@@ -474,8 +474,8 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
-    if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1, 4>(p, L, st);
-    else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1, 4>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1, 2>(p, L, st);
+    else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1, 2>(p, L, st);
     else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2, 2>(p, L, st);
     else if (L.t.bco == 64) rc = launch_cfg<E, 64, 256, 2, 2, 2>(p, L, st);
     else rc = launch_cfg<E, 32, 256, 1, 2, 2>(p, L, st);

@@ -200,7 +200,10 @@ template <> struct TapMma<BF16> {
 #endif
 constexpr int RING = MV2_C3_RING;
 static_assert(18 % RING == 0 && RING >= 2, "ring slots must divide the 18 fragments of a group");
-constexpr int HWT = 5;                                                // tap at which the prefetched halo goes into the idle image (HSPLIT = 0)
+#ifndef MV2_C3_HWT
+#define MV2_C3_HWT 5
+#endif
+constexpr int HWT = MV2_C3_HWT;                                       // tap at which the prefetched halo goes into the idle image (HSPLIT = 0); <= 7: tap 8 opens with the barrier
 
 template <typename E, bool FUSED>
 struct C3Lds {
