@@ -123,6 +123,19 @@ int mv2_conv_rms_ok(const mv2_conv_desc* desc);
 int mv2_conv_rms(const mv2_conv_desc* desc, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                  const float* bias, const void* residual, void* out, void* stream);
 
+/* mv2_conv_in — the encoder's input convolution (reference M:1109, 1557: CausalConv3d(channels -> 64, kt x 7 x 7)) over the pre-padded
+ * channel-last clip of mv2_video_to_ndhwc (4-channel bf16 pixels): `d` is the descriptor mv2_conv takes for the same launch (Ci = 4,
+ * kh = 7 row taps of kw = 1 "wide" tap each as pack.py::pack_conv_in lays them out, no padding, check_bounds = 0, input extents =
+ * output extents + (kt - 1, 6, 6), Wi even, co = out_c = 64, MV2_STORE_ROWS, no activation); mv2_conv_in_eligible() says whether it
+ * qualifies (else: mv2_conv).  A workgroup stages the kt halo frames of an 8 x 32 output tile in LDS once instead of gathering every
+ * input row once per (time, height) tap.
+ * wfrag: [kt][7 ih][2 steps s][2 channel tiles][64 lanes][8 bf16]: lane l holds, for output channel 32 tile + l % 32, the weights of
+ * pixels iw = 4 s + 2 (l / 32) + {0, 1} x 4 channels of tap (it, ih) (zero for iw = 7 and for channels the clip does not have):
+ * the A operand of v_mfma_f32_32x32x16_bf16; mv2_conv_in_weight_bytes(kt) bytes. */
+int mv2_conv_in_eligible(const mv2_conv_desc* d);
+size_t mv2_conv_in_weight_bytes(int kt);
+int mv2_conv_in(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wfrag, const float* bias, void* out, void* stream);
+
 /* mv2_conv_out — the decoder's output convolution (reference M:1127, 1642: CausalConv3d(dim -> channels, kt x 3 x 3), zero padding) as
  * an HBM stream: bf16, Ci = 64, co <= 4, kt <= 3, stride 1, 'same' in space / causal in time, fp32 NCTHW store with `crop_t` leading
  * frames dropped (MV2_STORE_NCTHW_F32).  `d` is the descriptor mv2_conv would take for the same layer (pt = kt - 1, ph = pw = 1,

@@ -39,6 +39,9 @@ _SIGS = {
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_conv_rms_ok': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_rms': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mv2_conv_in_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
+    'mv2_conv_in_weight_bytes': (C.c_size_t, [C.c_int]),
+    'mv2_conv_in': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mv2_conv_out_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_out_weight_bytes': (C.c_size_t, [C.c_int]),
     'mv2_conv_out': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -176,6 +179,17 @@ class HipOps:
         fn = self.lib.mv2_conv_rms
         args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wp), _ptr(segs), _ptr(bias), _ptr(residual), _ptr(out))
         return _mk(fn, args, 'mv2_conv_rms', (desc, x, wp, segs, bias, residual, out), [out])
+
+    def conv_in_eligible(self, d: dict) -> bool:
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv_in_eligible(C.byref(desc)))
+
+    def conv_in(self, d: dict, x, in_bytes, wfrag, bias, out):
+        desc = ConvDesc(**d)
+        assert wfrag.numel() * wfrag.element_size() == self.lib.mv2_conv_in_weight_bytes(d['kt'])
+        fn = self.lib.mv2_conv_in
+        args = (C.byref(desc), _ptr(x), in_bytes, _ptr(wfrag), _ptr(bias), _ptr(out))
+        return _mk(fn, args, 'mv2_conv_in', (desc, x, wfrag, bias, out), [out])
 
     def conv_out_eligible(self, d: dict) -> bool:
         desc = ConvDesc(**d)

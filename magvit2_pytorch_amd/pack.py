@@ -173,6 +173,19 @@ def pack_conv3d(w, bias, dtype, frag_major=False):
     return pc
 
 
+def pack_conv_in_frag(w):
+    """mv2_conv_in's weight image (include/mv2.h): w (64, ci <= 4, kt, 7, 7) -> [kt][7 ih][2 s][2 co tiles][64 lanes][8] bf16; lane l =
+    (co = 32 tile + l % 32, pixel pair l // 32); element j = (pixel iw = 4 s + 2 (l // 32) + j // 4, channel j % 4); iw = 7 and
+    missing channels are zero."""
+    co, ci, kt, kh, kw = w.shape
+    assert co == 64 and ci <= 4 and kh == 7 and kw == 7 and 1 <= kt <= 7
+    wt = torch.zeros(64, 4, kt, 7, 8)
+    wt[:, :ci, :, :, :7] = w.float()
+    # [tile][co32][c][it][ih][s][hi][p2]  (iw = 4 s + 2 hi + p2)  ->  [it][ih][s][tile][hi][co32][p2][c]
+    img = wt.reshape(2, 32, 4, kt, 7, 2, 2, 2).permute(3, 4, 5, 0, 6, 1, 7, 2).contiguous()
+    return img.reshape(kt * 7 * 2 * 2, 64, 8).to(torch.bfloat16)
+
+
 def pack_conv_out(w):
     """mv2_conv_out's weight image (include/mv2.h): w (co <= 4, 64, kt, 3, 3) -> [kt * 9 taps][2 halves][64 lanes][8] bf16 with
     lane l = (co = l % 16, channel group l // 16): the A operand of v_mfma_f32_16x16x32_bf16, zero rows for co >= w.shape[0]."""

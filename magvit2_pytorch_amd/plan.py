@@ -48,6 +48,9 @@ class PackedModel:
 
         put('conv_in', P.pack_conv_in(f('conv_in.conv.weight'), f('conv_in.conv.bias'), dtype, self.c_in_pad))
         put('conv_out', P.pack_conv3d(f('conv_out.conv.weight'), f('conv_out.conv.bias'), dtype))
+        wi = f('conv_in.conv.weight')
+        if dtype == torch.bfloat16 and self.c_in_pad == 4 and wi.shape[0] == 64 and tuple(wi.shape[3:]) == (7, 7) and wi.shape[2] <= 7:
+            self.frag['conv_in'] = dev(P.pack_conv_in_frag(wi))            # mv2_conv_in's fragment image (convin.hip)
         wo = f('conv_out.conv.weight')
         if dtype == torch.bfloat16 and wo.shape[1] == 64 and wo.shape[0] <= 4 and tuple(wo.shape[3:]) == (3, 3) and wo.shape[2] <= 3:
             self.frag['conv_out'] = dev(P.pack_conv_out(wo))               # mv2_conv_out's fragment image (convout.hip)
@@ -639,7 +642,20 @@ class Plan:
             else:
                 steps.append(ops.video_to_ndhwc(self.dt, video, padded, B, cfg['channels'], frames, H, W, pad_t, pad_hw, cp, tail))
                 self.step_names.append('video_to_ndhwc')
-            y = self._conv(steps, name, pm.convs[name], Act(padded, B, Tp, Hp, Wp, cp), To=To, Ho=H, Wo=W, check_bounds=False,
+            pc = pm.convs[name]
+            d = dict(dtype=self.dt, B=B, Ti=Tp, Hi=Hp, Wi=Wp, Ci=cp, To=To, Ho=H, Wo=W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1, pt=0, ph=0,
+                     pw=0, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=0, act=P.ACT_NONE,
+                     store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
+            if name in pm.frag and ops.conv_in_eligible(d) and not os.environ.get('MV2_NO_CONV_IN'):
+                # the halo-staged form (convin.hip): the input frames of a tile go to LDS once instead of one gather per (it, ih) tap
+                y = Act(self.arena.get(B * To * H * W * pc.co, self.dtype), B, To, H, W, pc.co)
+                steps.append(ops.conv_in(d, padded, padded.numel() * padded.element_size(), pm.frag[name], pc.bias, y.t))
+                steps[-1].label = name
+                self.step_flops[id(steps[-1])] = 2.0 * B * To * H * W * pc.co_real * pc.k_real
+                self.step_names.append(name)
+                self.arena.put(padded)
+                return y
+            y = self._conv(steps, name, pc, Act(padded, B, Tp, Hp, Wp, cp), To=To, Ho=H, Wo=W, check_bounds=False,
                            in_bytes=padded.numel() * padded.element_size())
             self.arena.put(padded)
             return y

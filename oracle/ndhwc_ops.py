@@ -55,6 +55,28 @@ class CpuOps:
     def conv_workspace_bytes(self, d):
         return 0
 
+    def conv_in_eligible(self, d) -> bool:
+        """mirror of mv2_conv_in_eligible (convin.hip)"""
+        return (d['dtype'] == 0 and d['Ci'] == 4 and d['co'] == 64 and d['out_c'] == 64 and d['kh'] == 7 and d['kw'] == 1 and 1 <= d['kt'] <= 7
+                and d['st'] == 1 and d['sh'] == 1 and d['sw'] == 1 and d['pt'] == 0 and d['ph'] == 0 and d['pw'] == 0 and d['check_bounds'] == 0
+                and d['Ti'] == d['To'] + d['kt'] - 1 and d['Hi'] == d['Ho'] + 6 and d['Wi'] == d['Wo'] + 6 and d['Wi'] % 2 == 0
+                and d['store'] == STORE_ROWS and d['act'] == 0)
+
+    def conv_in(self, d, x, in_bytes, wfrag, bias, out):
+        """mv2_conv_in: the dense kernel is read back from the fragment image; 'valid' convolution over the pre-padded clip"""
+        d = dict(d)
+        def step(stream):
+            B, Tp, Hp, Wp, kt = d['B'], d['Ti'], d['Hi'], d['Wi'], d['kt']
+            # [it][ih][s][tile][hi][co32][p2][c] -> w[co][c][it][ih][iw = 4 s + 2 hi + p2]
+            w = wfrag.to(self.acc).reshape(kt, 7, 2, 2, 2, 32, 2, 4).permute(3, 5, 7, 0, 1, 2, 4, 6).reshape(64, 4, kt, 7, 8)[..., :7]
+            xin = x[: B * Tp * Hp * Wp * 4].reshape(B, Tp, Hp, Wp, 4).permute(0, 4, 1, 2, 3).to(self.acc)
+            y = torch.nn.functional.conv3d(xin, w, None if bias is None else bias[:64].to(self.acc))      # (B, 64, To, Ho, Wo)
+            y = y.permute(0, 2, 3, 4, 1).reshape(-1)
+            out[: y.numel()].copy_(y.to(out.dtype))
+        step.outs = [out]
+        step.what = 'conv_in'
+        return step
+
     def conv_out_eligible(self, d) -> bool:
         """mirror of mv2_conv_out_eligible (convout.hip)"""
         return (d['dtype'] == 0 and d['Ci'] == 64 and 1 <= d['co'] <= 4 and d['kh'] == 3 and d['kw'] == 3 and 1 <= d['kt'] <= 3 and d['st'] == 1

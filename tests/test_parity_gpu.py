@@ -410,6 +410,39 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
 
 
+@pytest.mark.parametrize('B,T,H,W,ci,kt', [(1, 20, 128, 128, 3, 7), (2, 3, 20, 36, 3, 7), (1, 2, 9, 50, 4, 7), (3, 1, 16, 32, 1, 1), (1, 5, 8, 32, 3, 3)])
+def test_conv_in_kernel_vs_emulation(B, T, H, W, ci, kt):
+    """mv2_conv_in (convin.hip: halo frames of an 8 x 32 tile staged once, weight slice per time tap in LDS) against the dense
+    convolution the emulation runs from the same fragment image: ragged tiles in both directions, 1 / 3 / 4 input channels, kt 1 / 3 / 7."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + ci)
+    Tp, Hp, Wp = T + kt - 1, H + 6, W + 6
+    x = torch.zeros(B, Tp, Hp, Wp, 4)
+    x[..., :ci] = torch.randn(B, Tp, Hp, Wp, ci, generator=g)
+    x = x.reshape(-1).to(torch.bfloat16)
+    w = torch.randn(64, ci, kt, 7, 7, generator=g) / (ci * 49 * kt) ** 0.5
+    bias = torch.randn(64, generator=g) * 0.1
+    wf = PK.pack_conv_in_frag(w)
+    d = dict(dtype=PK.MV2_BF16, B=B, Ti=Tp, Hi=Hp, Wi=Wp, Ci=4, To=T, Ho=H, Wo=W, co=64, co_pad=128, st=1, sh=1, sw=1, pt=0, ph=0, pw=0, kt=kt,
+             kh=7, kw=1, nsteps=(kt * 7 + 1) // 2, seg_bytes=64, check_bounds=0, act=PK.ACT_NONE, store=PK.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0,
+             out_c=64, splitk=0)
+    assert ops.conv_in_eligible(d) and cpu.conv_in_eligible(d)
+    assert not ops.conv_in_eligible(dict(d, co=32, out_c=32)) and not ops.conv_in_eligible(dict(d, check_bounds=1)) and not ops.conv_in_eligible(dict(d, Wi=Wp + 1))
+    n = B * T * H * W * 64
+    out_c = torch.full((n,), float('nan'), dtype=torch.bfloat16)
+    cpu.conv_in(d, x, x.numel() * 2, wf, bias, out_c)(None)
+    dev = ops.device
+    out_g = torch.full((n,), float('nan'), dtype=torch.bfloat16, device=dev)
+    ops.conv_in(d, x.to(dev), x.numel() * 2, wf.to(dev), bias.to(dev), out_g)(ops.current_stream())
+    ops.synchronize()
+    a, b = out_g.cpu().float(), out_c.float()
+    assert torch.isfinite(a).all()
+    assert ((a - b).abs() <= 2 ** -7 * b.abs() + 2e-3).all(), (a - b).abs().max().item()          # one bf16 ulp of the fp32-accumulated value
+    assert (a != b).float().mean().item() < 0.02
+
+
 @pytest.mark.parametrize('B,T,H,W,co,kt,crop', [(1, 20, 128, 128, 3, 3, 3), (2, 5, 20, 36, 3, 3, 0), (1, 3, 9, 17, 4, 3, 2), (3, 1, 16, 16, 1, 1, 0),
                                                  (1, 4, 8, 16, 3, 2, 1)])
 def test_conv_out_kernel_vs_emulation(B, T, H, W, co, kt, crop):
