@@ -208,6 +208,13 @@ int main(int argc, char** argv) {
     ok &= run_case(20, 256, 512, false, 20, st);
     ok &= run_case(10, 256, 512, false, 20, st);
     ok &= run_case(5, 256, 512, false, 20, st);
+    if (argc > 2 && !strcmp(argv[2], "b4")) {      // the same levels at four clips per step (BASELINE configs[2] per-GPU shape)
+        ok &= run_case(80, 4096, 128, false, 10, st);
+        ok &= run_case(80, 1024, 256, false, 10, st);
+        ok &= run_case(80, 256, 512, false, 10, st);
+        ok &= run_case(40, 256, 512, false, 10, st);
+        ok &= run_case(20, 256, 512, false, 10, st);
+    }
     printf(ok ? "ALL OK\n" : "SOME FAILED\n");
     return ok ? 0 : 1;
 }
