@@ -3,7 +3,9 @@
 hot path (reference magvit2_pytorch.py:1045-1720), executing on MI355X through libmv2_hip.so.
 
 Kept from the reference: the keyword-only constructor and its layer-spec tuple grammar, the
-``state_dict`` key names and shapes (checkpoints load both ways), and the method surface
+``state_dict`` key names and shapes (checkpoints load both ways; one asymmetry: the reference ALWAYS builds its discriminator,
+M:1413-1422, so its ``state_dict`` always has ``discr.*`` keys, while ``use_gan=False`` here builds none — such a checkpoint loads
+into the reference with ``strict=False`` or after adding the reference's own ``discr.*`` entries), and the method surface
 ``encode / decode / tokenize / decode_from_code_indices / forward`` with the same tensor conventions
 (NCTHW video or NCHW image in, ids ``(B, T', H', W')`` int64 for LFQ / int32 for FSQ) and the same
 assertions.  ``forward(return_loss=True)`` returns the reconstruction + quantizer auxiliary losses and, with ``use_gan``, the

@@ -937,7 +937,7 @@ def test_attention_dropout_is_refused_in_training_mode_only():
 def test_tokenize_stream_matches_plain_loop():
     """streaming.tokenize_stream (uploads / downloads on a side stream on the GPU) yields, in order, what tokenize() gives clip by clip;
     on the CPU backend it is the plain loop, which is what this checks — the stream / event choreography has a GPU twin in
-    tests/gpu_extra_random_specs.py."""
+    tests/test_zz_widen_gpu.py."""
     from magvit2_pytorch_amd.streaming import tokenize_stream
     g = Golden('small_lfq')
     tok = emulated_tokenizer(g.kw, g.weights(), torch.float32)

@@ -1,6 +1,5 @@
-"""GPU twin of tests/test_host_logic.py::test_random_specs — NOT collected by default (the file name does not match test_*.py):
-run it explicitly, `python -m pytest tests/gpu_extra_random_specs.py -m gpu -q`, as tools/gpu_round3_first.sh does.  It was written
-when no GPU minutes were left to execute it; once it has passed on an MI355X it moves into tests/test_zz_widen_gpu.py.
+"""GPU twin of tests/test_host_logic.py::test_random_specs, plus the lockstep tests of the two kernels that were first written without GPU
+access (mv2_pad_ndhwc, mv2_gateloop_scan).  Collected by default since round 3 (first passed on an MI355X in the round's first GPU call).
 
 Per seed: a random layer spec / kernel sizes / channel count / quantizer / clip mode (the generator of the CPU test, wider channel
 ranges so that the conv3 / pw_se kernels take part), the HIP plan against the kernel emulation launch by launch (fp32 and bf16),
