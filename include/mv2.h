@@ -110,6 +110,10 @@ typedef struct mv2_conv_desc {
 } mv2_conv_desc;
 
 size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d);
+/* 1 when mv2_conv / mv2_conv_rms run this descriptor on the LDS-DMA pointwise kernel (conv.hip conv_pw_dma_kernel: bf16, 1x1x1, stride 1,
+ * un-padded, whole 128-byte K steps, staged stores, >= 256 tiles of 128 x 128): same operands, same results, never splits K.  Introspection
+ * for tests and profiles; callers need not ask. */
+int mv2_conv_pointwise_dma(const mv2_conv_desc* d);
 int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
              const float* bias, const float* rowscale, const void* residual, void* out,
              void* workspace, size_t workspace_bytes, void* stream);

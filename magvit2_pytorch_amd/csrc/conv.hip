@@ -325,6 +325,143 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         }
 }
 
+// ------------------------------------------------------------------------------- pointwise kernel: LDS-DMA staging
+// 1x1x1, stride-1, un-padded convolutions over whole 128-byte K steps (the feed-forward / projection / up-sampling GEMMs of the path:
+// reference magvit2_pytorch.py:298-339 FeedForward, :380-470 the attention projections, :760-800 the up-sampling convs) are plain
+// GEMMs: input row == output row, nothing to gather and nothing to mask.  For them the VGPR round trip of conv_kernel (16 B loads ->
+// registers -> ds_write -> barrier) is pure overhead: profiles/r03_generic_default_phase_clocks.log has its K loop at 27 % of the MFMA
+// rate with the LDS-write path and the L1s both half busy.  Here both operands go global -> LDS DIRECTLY (buffer_load ... lds): a
+// wave-instruction fills 8 rows x 128 bytes of a stage (lane l -> row l / 8, 16-byte slot l % 8) and the XOR swizzle of the stage
+// image (the one conv_kernel writes) is applied on the SOURCE side: slot s of row r receives global chunk s ^ ((r >> 1) & 7).
+// No staging registers, no ds_write; the waits are hand-placed (a __syncthreads() would wait for vmcnt(0) and drain the pipeline),
+// one bare s_barrier per step.  Same packed weights, same MFMA order, same epilogue: results are bit-identical to conv_kernel's.
+// Measured on MI355X (profiles/r03_pw_dma.log, prototype tools/experiments/pw_dma_bench.cpp): ff1 C=512 32.8 -> 22.7 us,
+// ff2 21.7 -> 16.5, ff1 C=256 41.4 -> 31.6, ff2 22.1 -> 14.6, qkv 13.8 -> 9.5, out 8.9 -> 6.0, kv 13.2 -> 8.2, up 128->256 46 -> 19.
+// (prototype figures, trivial epilogue; behind the real epilogue and inside the step graph the gain is smaller, see pw_dma_ok below).
+template <int N_> struct WaitVm;
+#define MV2_WAITVM(n) template <> struct WaitVm<n> { static __device__ __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } };
+MV2_WAITVM(0) MV2_WAITVM(8)
+#undef MV2_WAITVM
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int NS, bool RMS>
+__global__ __launch_bounds__(256, 2) void conv_pw_dma_kernel(const ConvParams p) {
+    typedef BF16 E;
+    constexpr int BCO = 128, BPOS = 128, WCO = 2, WPOS = 2;
+    constexpr int STAGE = (BCO + BPOS) * 128;
+    constexpr int LPS = (BCO + BPOS) * 8 / 256;                  // DMA loads per thread and step: 4 weight + 4 activation
+    static_assert(NS == 2 || NS == 3, "vmcnt immediates below");      // the library launches NS = 2 (launch_dtype)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const mv2_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wpos = wave & 1;
+    int bid = blockIdx.x;
+    {   // XCD-aware: blocks of one XCD walk neighbouring tiles (as conv_kernel)
+        const int nblk = p.n_co_tiles * p.n_pos_tiles;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int co_tile = bid % p.n_co_tiles, pos_tile = bid / p.n_co_tiles;
+    const int n0 = co_tile * BCO;
+    const int64_t m0 = (int64_t)pos_tile * BPOS;
+    const int nsteps = d.nsteps;
+    // epilogue operands that only depend on the tile: requested now, their round trip hides under the K loop
+    const float bias_pf = (p.bias && tid < BCO && n0 + tid < d.co_pad) ? p.bias[n0 + tid] : 0.f;
+    const float rs_pf = (p.rowscale && tid < BPOS && m0 + tid < p.M) ? p.rowscale[m0 + tid] : 1.f;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.w_bytes, 0x00020000);
+    // per-thread source offsets: load i covers rows 8 (wave + 4 i) + lane / 8 of the stage image [weight rows BCO | position rows BPOS].
+    // Rows past M read the out-of-range offset (no memory access); what lands in their LDS rows only reaches output rows that are never stored.
+    uint32_t voff[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int row = 8 * (wave + 4 * i) + (lane >> 3);
+        const uint32_t chunk = (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+        if (i < LPS / 2) voff[i] = (uint32_t)(n0 + row) * 128u + chunk;
+        else {
+            const int64_t m = m0 + row - BCO;
+            voff[i] = m < p.M ? (uint32_t)m * (uint32_t)d.Ci * 2u + chunk : p.in_bytes;
+        }
+    }
+    const uint32_t w_step = (uint32_t)d.co_pad * 128u;
+    auto issue = [&](int s, int stage) {          // every load unconditional: steps past the end read out of range (the check does not see soffset)
+        const bool live = s < nsteps;
+        const uint32_t so_w = live ? (uint32_t)s * w_step : 0u, so_x = live ? (uint32_t)s * 128u : 0u;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + 8 * (wave + 4 * i) * 128);
+            if (i < LPS / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, (int)(live ? voff[i] : p.w_bytes), (int)so_w, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, (int)(live ? voff[i] : p.in_bytes), (int)so_x, 0, 0);
+        }
+    };
+    f32x16 acc[WCO][WPOS];
+#pragma unroll
+    for (int a = 0; a < WCO; ++a)
+#pragma unroll
+        for (int b = 0; b < WPOS; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float rss[WPOS];                                             // RMS: sum of squares of this lane's chunks of rows b * 32 + l31 (waves wco == 0)
+#pragma unroll
+    for (int b = 0; b < WPOS; ++b) rss[b] = 0.f;
+    const uint32_t swz = (uint32_t)((l31 >> 1) & 7);
+    const uint32_t rd_w = (uint32_t)(wco * 32 * WCO + l31) * 128u, rd_p = (uint32_t)(BCO + wpos * 32 * WPOS + l31) * 128u;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);                // prologue: NS - 1 steps in flight
+    int stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        WaitVm<(NS - 2) * LPS>::run();                           // this thread's loads of step s have landed ...
+        __builtin_amdgcn_s_barrier();                            // ... everybody's, and everybody has read the stage that is refilled next
+        const int nxt = stage == 0 ? NS - 1 : stage - 1;         // (s + NS - 1) % NS
+        issue(s + NS - 1, nxt);
+        const char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t ck = (uint32_t)(((ks * 2 + hi) ^ swz) << 4);
+            i32x4 fw[WCO], fp[WPOS];
+#pragma unroll
+            for (int a = 0; a < WCO; ++a) fw[a] = *(const i32x4*)(base + rd_w + a * 32 * 128 + ck);
+#pragma unroll
+            for (int b = 0; b < WPOS; ++b) fp[b] = *(const i32x4*)(base + rd_p + b * 32 * 128 + ck);
+#pragma unroll
+            for (int a = 0; a < WCO; ++a)
+#pragma unroll
+                for (int b = 0; b < WPOS; ++b) Mma<E>::run(fw[a], fp[b], acc[a][b]);
+            if constexpr (RMS) {
+                if (wco == 0) {                                  // wave-uniform: the two waves of a position half read the same rows
+#pragma unroll
+                    for (int b = 0; b < WPOS; ++b) {
+                        // NB bit_cast of the WHOLE fragment, then element pairs: __builtin_bit_cast(bf16x2, fp[b][q]) on a vector element
+                        // compiles to element 0 for every q (hipcc 7.2, seen in the ISA)
+                        const bf16x8 h = __builtin_bit_cast(bf16x8, fp[b]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bf16x2 v = {h[2 * q], h[2 * q + 1]};
+                            rss[b] = __builtin_amdgcn_fdot2_f32_bf16(v, v, rss[b], false);
+                        }
+                    }
+                }
+            }
+        }
+        stage = stage == NS - 1 ? 0 : stage + 1;
+    }
+    WaitVm<0>::run();
+    __syncthreads();                                             // every DMA write has landed, every fragment read is done: LDS is free
+    if constexpr (RMS) {    // lanes l31 and l31 + 32 hold the two halves of a row's chunks: fold, one lane per row publishes 1 / |row|
+        float* rs_lds = (float*)(smem + StageCfg<E, BCO, BPOS>::kRowScale);
+        if (wco == 0) {
+#pragma unroll
+            for (int b = 0; b < WPOS; ++b) {
+                float ss = rss[b];
+                ss += __shfl_xor(ss, 32, 64);
+                if (hi == 0) rs_lds[wpos * 32 * WPOS + b * 32 + l31] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            }
+        }
+    }
+    staged_epilogue<E, BCO, BPOS, WCO, WPOS>(p, smem, acc, n0, wco, wpos, tid, [&](int lp) { return m0 + lp; }, true, RMS, true, rs_pf, bias_pf);
+}
+
 // split-K finish: sum the fp32 slabs and run the same epilogue
 template <typename E>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const ConvParams p) {
@@ -398,8 +535,30 @@ inline TileCfg pick_tile(const mv2_conv_desc& d) {
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// conv_pw_dma_kernel instead of conv_kernel: bf16 1x1x1 stride-1 un-padded convolutions over whole 128-byte K steps of contiguous input
+// rows, stored through the staged epilogue, with at least 256 tiles of 128 x 128 (one per CU of an MI355X).  Below that the launch is one
+// round of workgroups whose length is the serial chain prologue -> K loop -> epilogue of ONE tile, and the 64 x 64 tiles of conv_kernel
+// (a quarter of that chain, four times the workgroups) win: in-graph A/B on one box (profiles/r03_pw_dma_bench_ab.log), whole step at
+// B = 1: kernel off 2.905 ms, threshold 64: 2.932, 128: 2.922, 256: 2.880; B = 4: 7.90 -> 7.79 ms.  The launch never splits K.
+// A pure function of the descriptor; oracle/ndhwc_ops.py::CpuOps._pw_dma restates it.
+inline bool pw_dma_ok(const mv2_conv_desc& d) {
+    int min_blocks = 256;
+#ifdef MV2_EXPERIMENTS
+    if (getenv("MV2_TILE")) return false;                                        // tools/k3_bench tile sweep of conv_kernel
+    if (const char* e = getenv("MV2_PW_DMA")) { min_blocks = atoi(e); if (min_blocks <= 0) return false; }   // 0 = off, N = block threshold
+#endif
+    if (d.dtype != MV2_BF16 || d.splitk > 1) return false;
+    if (!(d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0 &&
+          d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi)) return false;
+    if (d.seg_bytes != 128 || d.Ci % 64 != 0 || d.nsteps != d.Ci / 64) return false;
+    if (d.store == MV2_STORE_NCTHW_F32 || (d.out_c * 2) % 16 != 0 || d.co % 8 != 0) return false;                   // stage_ok
+    const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
+    return ((d.co + 127) / 128) * ((M + 127) / 128) >= min_blocks;
+}
+
 struct Launch {
     TileCfg t;
+    bool dma;             // conv_pw_dma_kernel
     int n_co_tiles, n_pos_tiles, splitk, steps_per_split;
     int64_t M, ws_rows;
     int ws_cols;
@@ -432,10 +591,11 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     Launch L;
     L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
-    L.t = pick_tile(d);
+    L.dma = pw_dma_ok(d);
+    L.t = L.dma ? TileCfg{128, 128} : pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
-    int sk = d.splitk;
+    int sk = L.dma ? 1 : d.splitk;
     if (sk <= 0) {
         sk = 1;
         const int64_t blocks = (int64_t)L.n_co_tiles * L.n_pos_tiles;
@@ -471,9 +631,29 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
     return MV2_OK;
 }
 
+template <int NS, bool RMS>
+int launch_pw_dma(const ConvParams& p, const Launch& L, hipStream_t st) {
+    constexpr size_t lds_main = (size_t)NS * 256 * 128, lds_epi = (size_t)StageCfg<BF16, 128, 128>::kBytes;
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    hipError_t e = hipFuncSetAttribute((const void*)conv_pw_dma_kernel<NS, RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv_pw_dma_kernel<NS, RMS>), dim3((unsigned)(L.n_co_tiles * L.n_pos_tiles)), dim3(256), lds, st, p);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
 template <typename E>
 int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
+    if (L.dma) {
+        if constexpr (std::is_same<E, BF16>::value) {
+            // two stages = 64 KB of LDS = two workgroups per CU: measured better than three stages (96 KB, one workgroup per CU) on every
+            // launch with more than one tile per CU (profiles/r03_pw_dma.log: ff1 22.7 vs 29.9 us, ff2 at B = 4 47.3 vs 50.8)
+            return p.rms_fused ? launch_pw_dma<2, true>(p, L, st) : launch_pw_dma<2, false>(p, L, st);
+        } else {
+            return MV2_EINVAL;
+        }
+    }
     if (L.t.bco == 64 && L.t.bpos == 64) rc = launch_cfg<E, 64, 64, 1, 1, 2>(p, L, st);
     else if (L.t.bco == 64 && L.t.bpos == 128) rc = launch_cfg<E, 64, 128, 2, 1, 2>(p, L, st);
     else if (L.t.bco == 128) rc = launch_cfg<E, 128, 128, 2, 2, 2>(p, L, st);
@@ -503,6 +683,8 @@ extern "C" size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d) {
 static int conv_impl(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                      const float* bias, const float* rowscale, const void* residual, void* out,
                      void* workspace, size_t workspace_bytes, void* stream, int rms_fused);
+
+extern "C" int mv2_conv_pointwise_dma(const mv2_conv_desc* d) { return d && validate(*d) == MV2_OK && pw_dma_ok(*d) ? 1 : 0; }
 
 extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                         const float* bias, const float* rowscale, const void* residual, void* out,

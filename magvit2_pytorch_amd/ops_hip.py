@@ -37,6 +37,7 @@ _SIGS = {
     'mv2_conv_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mv2_conv_pointwise_dma': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_rms_ok': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_rms': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mv2_conv_in_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
@@ -169,6 +170,11 @@ class HipOps:
         keep = (desc, x, wp, segs, bias, rowscale, residual, out, ws)
 
         return _mk(fn, args, 'mv2_conv', keep, [out, ws])
+
+    def conv_pointwise_dma(self, d: dict) -> bool:
+        """does mv2_conv / mv2_conv_rms run this descriptor on the LDS-DMA pointwise kernel (introspection for tests)"""
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv_pointwise_dma(C.byref(desc)))
 
     def conv_rms_ok(self, d: dict) -> bool:
         desc = ConvDesc(**d)

@@ -100,12 +100,29 @@ class CpuOps:
         step.what = 'conv_out'
         return step
 
+    @staticmethod
+    def _pw_dma(d) -> bool:
+        """mirror of pw_dma_ok (conv.hip): which launches of mv2_conv / mv2_conv_rms run conv_pw_dma_kernel (128 x 128 tiles, no split-K)"""
+        if d['dtype'] != 0 or d.get('splitk', 0) > 1:
+            return False
+        if not (d['kt'] == d['kh'] == d['kw'] == 1 and d['st'] == d['sh'] == d['sw'] == 1 and d['pt'] == d['ph'] == d['pw'] == 0
+                and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi']):
+            return False
+        if d['seg_bytes'] != 128 or d['Ci'] % 64 != 0 or d['nsteps'] != d['Ci'] // 64:
+            return False
+        if d['store'] == STORE_NCTHW_F32 or (d['out_c'] * 2) % 16 != 0 or d['co'] % 8 != 0:
+            return False
+        M = d['B'] * d['To'] * d['Ho'] * d['Wo']
+        return -(-d['co'] // 128) * -(-M // 128) >= 256
+
     def conv_rms_ok(self, d) -> bool:
         """mirror of mv2_conv_rms_ok (conv.hip): staged-store shapes whose launch plan keeps the reduction in one workgroup.  The
         launch plan (pick_tile / plan_launch) is restated here so that the emulated plan has the launches of the HIP plan."""
         es = 2 if d['dtype'] == 0 else 4
         if d['store'] == STORE_NCTHW_F32 or (d['out_c'] * es) % 16 != 0 or d['co'] % (16 // es) != 0:
             return False
+        if self._pw_dma(d):
+            return True                          # the LDS-DMA pointwise kernel never splits K
         M = d['B'] * d['To'] * d['Ho'] * d['Wo']
         co, cus = d['co'], self.cus
         blocks128 = -(-co // 128) * -(-M // 128)

@@ -47,6 +47,19 @@ int main(void) {
         if (mv2_conv_out_weight_bytes(3) != 54 * 1024 || mv2_conv_out_weight_bytes(4) != 0) return 15;
         if (mv2_conv_out(&o, NULL, 0, NULL, NULL, NULL, NULL) == MV2_OK) return 16;
     }
+    /* which pointwise launches take the LDS-DMA kernel: a pure function of the descriptor (feed-forward in of the C = 512 level: yes;
+     * the same GEMM over a 16-row clip, a 3x3 kernel, fp32: no) */
+    {
+        mv2_conv_desc q = d;
+        q.Ti = q.To = 20; q.Hi = q.Ho = q.Wi = q.Wo = 16; q.Ci = 512; q.co = 2816; q.co_pad = 2816; q.kt = q.kh = q.kw = 1; q.pt = q.ph = q.pw = 0;
+        q.nsteps = 8; q.seg_bytes = 128; q.check_bounds = 0; q.act = MV2_ACT_GEGLU; q.store = MV2_STORE_ROWS; q.out_c = 1408;
+        if (!mv2_conv_pointwise_dma(&q) || !mv2_conv_rms_ok(&q) || mv2_conv_workspace_bytes(&q) != 0) return 17;
+        mv2_conv_desc r = q; r.Ti = r.To = 1; r.Hi = r.Ho = r.Wi = r.Wo = 4;
+        if (mv2_conv_pointwise_dma(&r)) return 18;
+        r = q; r.dtype = MV2_F32;
+        if (mv2_conv_pointwise_dma(&r)) return 19;
+        if (mv2_conv_pointwise_dma(&d)) return 20;
+    }
     free(w); free(a); free(b);
     printf("abi smoke ok (%zu byte image, %d strips)\n", bytes, strips);
     return 0;

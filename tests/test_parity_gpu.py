@@ -410,6 +410,67 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
 
 
+@pytest.mark.parametrize('case', ['rows_residual', 'geglu_rms', 'shuffle_silu', 'long_k_residual', 'edge_256_rms', 'below_threshold'])
+def test_pointwise_dma_kernel_vs_emulation(case):
+    """conv_pw_dma_kernel (conv.hip: both GEMM operands global -> LDS by buffer_load ... lds, hand-placed waits) behind mv2_conv /
+    mv2_conv_rms against the emulation: plain rows + residual with a ragged last tile, GEGLU with the RMSNorm row scale computed in the
+    launch, depth-to-space store + SiLU (the up-sampling conv), a 22-step K loop, exactly 256 tiles (the threshold) with the row scale;
+    the last case has 160 tiles and stays on conv_kernel (the rule is checked on both sides: library and its restatement)."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    T, H, W, Ci, co_ref, act, store, shuffle, res, rms, dma = {
+        'rows_residual': (20, 29, 29, 704, 256, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, True),      # 132 x 2 tiles, 11 steps
+        'geglu_rms': (3, 32, 32, 256, 2 * 680, PK.ACT_GEGLU, PK.STORE_ROWS, (1, 1, 1), False, True, True),       # 24 x 11 tiles, hidden 680 -> 704
+        'shuffle_silu': (17, 32, 32, 128, 512, PK.ACT_SILU, PK.STORE_SHUFFLE, (1, 2, 2), False, False, True),    # 136 x 4 tiles, 2 steps
+        'long_k_residual': (32, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, True),    # 64 x 4 = 256 tiles, 22 steps
+        'edge_256_rms': (16, 32, 32, 640, 256, PK.ACT_ELU, PK.STORE_ROWS, (1, 1, 1), False, True, True),         # 128 x 2 = 256 tiles, 10 steps
+        'below_threshold': (20, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, False),   # 40 x 4 = 160 tiles: conv_kernel
+    }[case]
+    M = T * H * W
+    w2d = torch.randn(co_ref, Ci, generator=g) / Ci ** 0.5
+    bias = torch.randn(co_ref, generator=g) * 0.1
+    gamma = torch.full((Ci,), float(Ci) ** 0.5) if rms else None      # RMSNorm's gamma * sqrt(dim), folded into the weights as the plan does
+    if act == PK.ACT_GEGLU:
+        pc, hidden = PK.pack_geglu_in(w2d, bias, torch.bfloat16, in_scale=gamma)
+        out_c = hidden
+    elif store == PK.STORE_SHUFFLE:
+        pc = PK.pack_shuffle_up(w2d, bias, torch.bfloat16, shuffle[0] * shuffle[1] * shuffle[2])
+        out_c = pc.co // (shuffle[0] * shuffle[1] * shuffle[2])
+    else:
+        pc = PK.pack_pointwise(w2d, bias, torch.bfloat16, in_scale=gamma)
+        out_c = pc.co
+    rt, rh, rw = shuffle
+    d = dict(dtype=PK.MV2_BF16, B=1, Ti=T, Hi=H, Wi=W, Ci=Ci, To=T, Ho=H, Wo=W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
+             kt=1, kh=1, kw=1, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=0, act=act, store=store, rt=rt, rh=rh, rw=rw, crop_t=0,
+             out_c=out_c, splitk=0)
+    assert ops.conv_pointwise_dma(d) == dma and cpu._pw_dma(d) == dma
+    assert not ops.conv_pointwise_dma(dict(d, dtype=PK.MV2_F32)) and not ops.conv_pointwise_dma(dict(d, splitk=2))
+    if rms:
+        assert ops.conv_rms_ok(d) and cpu.conv_rms_ok(d)
+    assert ops.conv_workspace_bytes(d) == 0
+    x = torch.randn(M * Ci, generator=g).to(torch.bfloat16)
+    n_out = M * rt * rh * rw * out_c
+    r = torch.randn(n_out, generator=g).to(torch.bfloat16) if res else None
+    dev = ops.device
+    segs_c, segs_g = pc.segs_tensor(H, W, Ci, 'cpu'), pc.segs_tensor(H, W, Ci, dev)
+    out_c_ = torch.full((n_out,), float('nan'), dtype=torch.bfloat16)
+    out_g = torch.full((n_out,), float('nan'), dtype=torch.bfloat16, device=dev)
+    xg, wg, bg, rg = x.to(dev), pc.wp.to(dev), pc.bias.to(dev), None if r is None else r.to(dev)
+    if rms:
+        cpu.conv_rms(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, r, out_c_)(None)
+        ops.conv_rms(d, xg, x.numel() * 2, wg, segs_g, bg, rg, out_g)(ops.current_stream())
+    else:
+        cpu.conv(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, None, r, out_c_, None)(None)
+        ops.conv(d, xg, x.numel() * 2, wg, segs_g, bg, None, rg, out_g, None)(ops.current_stream())
+    ops.synchronize()
+    a, b = out_g.cpu().float(), out_c_.float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert ((a - b).abs() <= 2 ** -7 * b.abs() + 4e-3).all(), (a - b).abs().max().item()          # one bf16 ulp of the fp32-accumulated value
+    assert (a != b).float().mean().item() < 0.03
+
+
 @pytest.mark.parametrize('B,T,H,W,ci,kt', [(1, 20, 128, 128, 3, 7), (2, 3, 20, 36, 3, 7), (1, 2, 9, 50, 4, 7), (3, 1, 16, 32, 1, 1), (1, 5, 8, 32, 3, 3)])
 def test_conv_in_kernel_vs_emulation(B, T, H, W, ci, kt):
     """mv2_conv_in (convin.hip: halo frames of an 8 x 32 tile staged once, weight slice per time tap in LDS) against the dense

@@ -123,12 +123,106 @@ __global__ __launch_bounds__(256, 2) void pw_dma_kernel(const P p) {
     }
 }
 
+// ---- variant: K step = 32 channels (64-byte rows), so that NS stages cost half the LDS: NS = 4 is 64 KB (two workgroups per CU, as NS = 2
+// above) with a prefetch distance of three half-steps instead of two.  A wave-instruction fills 16 rows x 64 bytes; swizzle over the four
+// 16-byte slots of a row: slot p of row r receives chunk p ^ ((r >> 2) & 3) (conflict-free for the 16-lane groups of ds_read_b128).
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void pw_dma32_kernel(const P p) {
+    constexpr int WM = BM / 64, WN = BN / 64;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int LPS = (BM + BN) * 4 / 256;                     // DMA loads per thread and half-step
+    static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nhalf = p.K / 32;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+    uint32_t voff[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int row = 16 * (wave + 4 * i) + (lane >> 2);       // row inside the stage image [W rows BN | X rows BM]
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < BN) { const int n = n0 + row; voff[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + chunk * 16u : p.wbytes; }
+        else { const int m = m0 + row - BN; voff[i] = m < p.M ? (uint32_t)m * (uint32_t)p.K * 2u + chunk * 16u : p.xbytes; }
+    }
+    auto issue = [&](int t, int stage) {
+        const bool live = t < nhalf;
+        const uint32_t so = live ? (uint32_t)t * 64u : 0u;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int rowbase = 16 * (wave + 4 * i);
+            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + rowbase * 64);
+            if (rowbase < BN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, (int)(live ? voff[i] : p.wbytes), (int)so, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, (int)(live ? voff[i] : p.xbytes), (int)so, 0, 0);
+        }
+    };
+    f32x16 acc[WN][WM];
+#pragma unroll
+    for (int a = 0; a < WN; ++a)
+#pragma unroll
+        for (int b = 0; b < WM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const uint32_t swz = (uint32_t)((l31 >> 2) & 3);
+    const uint32_t rd_w = (uint32_t)(wn * 32 * WN + l31) * 64u, rd_x = (uint32_t)(BN + wm * 32 * WM + l31) * 64u;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t, t);
+    int stage = 0;
+    for (int t = 0; t < nhalf; ++t) {
+        WaitVm<(NS - 2) * LPS>::run();
+        __builtin_amdgcn_s_barrier();
+        issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+        const char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t ck = (uint32_t)(((ks * 2 + hi) ^ swz) << 4);
+            i32x4 fw[WN], fx[WM];
+#pragma unroll
+            for (int a = 0; a < WN; ++a) fw[a] = *(const i32x4*)(base + rd_w + a * 32 * 64 + ck);
+#pragma unroll
+            for (int b = 0; b < WM; ++b) fx[b] = *(const i32x4*)(base + rd_x + b * 32 * 64 + ck);
+#pragma unroll
+            for (int a = 0; a < WN; ++a)
+#pragma unroll
+                for (int b = 0; b < WM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[a]), __builtin_bit_cast(bf16x8, fx[b]), acc[a][b], 0, 0, 0);
+        }
+        stage = stage == NS - 1 ? 0 : stage + 1;
+    }
+    WaitVm<0>::run();
+    __syncthreads();
+    constexpr int PITCH = BN * 2 + 16;
+#pragma unroll
+    for (int a = 0; a < WN; ++a)
+#pragma unroll
+        for (int b = 0; b < WM; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = (wn * WN + a) * 32 + 8 * g + 4 * hi, row = (wm * WM + b) * 32 + l31;
+                i32x2 v;
+                v[0] = (int)((unsigned)f2bf(acc[a][b][4 * g]) | ((unsigned)f2bf(acc[a][b][4 * g + 1]) << 16));
+                v[1] = (int)((unsigned)f2bf(acc[a][b][4 * g + 2]) | ((unsigned)f2bf(acc[a][b][4 * g + 3]) << 16));
+                *(i32x2*)(smem + row * PITCH + col * 2) = v;
+            }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, ch = q % CPR, m = m0 + row, n = n0 + ch * 8;
+        if (m < p.M && n < p.N) *(i32x4*)((char*)p.c + ((size_t)m * p.N + n) * 2) = *(const i32x4*)(smem + row * PITCH + ch * 16);
+    }
+}
+
 static uint32_t rng = 12345u;
 static inline float frand() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 32768.0f - 1.0f; }
 static inline uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static inline float h_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool HALF = false>
 static void run(const char* name, int M, int N, int K, int reps) {
     std::vector<uint16_t> x((size_t)M * K), w((size_t)N * K), c((size_t)M * N);
     for (auto& v : x) v = h_f2bf(frand());
@@ -138,11 +232,13 @@ static void run(const char* name, int M, int N, int K, int reps) {
     CK(hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dc, 0xff, c.size() * 2));
     P p{dx, dw, dc, M, N, K, (uint32_t)(x.size() * 2), (uint32_t)(w.size() * 2)};
-    constexpr int STAGE = (BM + BN) * 128, EPI = BM * (BN * 2 + 16);
+    constexpr int STAGE = (BM + BN) * (HALF ? 64 : 128), EPI = BM * (BN * 2 + 16);
     const int lds = NS * STAGE > EPI ? NS * STAGE : EPI;
-    CK(hipFuncSetAttribute((const void*)pw_dma_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    void (*kern)(const P);
+    if constexpr (HALF) kern = pw_dma32_kernel<BM, BN, NS>; else kern = pw_dma_kernel<BM, BN, NS>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL((pw_dma_kernel<BM, BN, NS>), dim3(blocks), dim3(256), lds, 0, p);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(c.data(), dc, c.size() * 2, hipMemcpyDeviceToHost));
     // check 4096 sampled elements against fp64
@@ -157,13 +253,13 @@ static void run(const char* name, int M, int N, int K, int reps) {
         if (d > 0.02 + 0.01 * fabs(ref)) ++bad;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((pw_dma_kernel<BM, BN, NS>), dim3(blocks), dim3(256), lds, 0, p);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, p);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pw_dma_kernel<BM, BN, NS>), dim3(blocks), dim3(256), lds, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1000.0 / reps;
-    printf("%-28s tile %3dx%-3d stages %d  M=%-6d K=%-5d N=%-5d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, BM, BN, NS, M, K, N, us,
+    printf("%-28s tile %3dx%-3d %s stages %d  M=%-6d K=%-5d N=%-5d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, BM, BN, HALF ? "k32" : "k64", NS, M, K, N, us,
            2.0 * M * N * K / us / 1e6, maxd, bad, blocks, lds / 1024);
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dc));
 }
@@ -178,10 +274,11 @@ int main() {
     for (const S& s : shapes) {
         run<128, 128, 2>(s.name, s.M, s.N, s.K, 50);
         run<128, 128, 3>(s.name, s.M, s.N, s.K, 50);
-        run<128, 128, 4>(s.name, s.M, s.N, s.K, 50);
+        run<128, 128, 3, true>(s.name, s.M, s.N, s.K, 50);
+        run<128, 128, 4, true>(s.name, s.M, s.N, s.K, 50);
+        run<128, 128, 6, true>(s.name, s.M, s.N, s.K, 50);
         run<64, 64, 4>(s.name, s.M, s.N, s.K, 50);
-        run<64, 128, 4>(s.name, s.M, s.N, s.K, 50);
-        run<128, 64, 4>(s.name, s.M, s.N, s.K, 50);
+        run<64, 64, 8, true>(s.name, s.M, s.N, s.K, 50);
     }
     return 0;
 }

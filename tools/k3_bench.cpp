@@ -373,7 +373,10 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
 }
 
 // generic mv2_conv (conv.hip) on a 1x1x1 convolution = plain GEMM rows x Ci -> Co: timing + phase clocks
-static void time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st) {
+typedef int (*convrms_fn)(const mv2_conv_desc*, const void*, size_t, const void*, const mv2_seg*, const float*, const void*, void*, void*);
+static convrms_fn p_conv_rms = nullptr;
+static float time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st, bool rms = false, int shuf = 1,
+                            std::vector<uint16_t>* keep = nullptr) {
     typedef int (*setprof_fn2)(void*);
     static setprof_fn2 p_cvprof = nullptr; static bool looked = false;
     if (!looked) { looked = true; p_cvprof = (setprof_fn2)dlsym(RTLD_DEFAULT, "mv2_conv_set_profile"); }
@@ -382,17 +385,23 @@ static void time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, in
     d.dtype = MV2_BF16; d.B = 1; d.Ti = d.To = rows_t; d.Hi = d.Ho = rows_hw; d.Wi = d.Wo = rows_hw; d.Ci = Ci; d.co = Co; d.co_pad = co_pad;
     d.st = d.sh = d.sw = 1; d.kt = d.kh = d.kw = 1; d.nsteps = nsteps; d.seg_bytes = 128; d.check_bounds = 0; d.act = act; d.store = MV2_STORE_ROWS;
     d.rt = d.rh = d.rw = 1; d.out_c = act == MV2_ACT_GEGLU ? Co / 2 : Co;
+    if (shuf > 1) { d.store = MV2_STORE_SHUFFLE; d.rh = d.rw = shuf; d.out_c = Co / (shuf * shuf); }
     const size_t M = (size_t)rows_t * rows_hw * rows_hw;
+    rng_state = 12345u;                                  // same operands on every call (ab_pointwise compares two runs)
     std::vector<uint16_t> hin(M * Ci), hw((size_t)nsteps * co_pad * 64);
     for (auto& v : hin) v = f2bf(frand()); for (auto& v : hw) v = f2bf(frand() * 0.05f);
     std::vector<mv2_seg> segs(nsteps); for (int i = 0; i < nsteps; ++i) { segs[i].elem_offset = i * 64; segs[i].sel = 1u | (1u << 8) | (1u << 16); }
     std::vector<float> bias(co_pad, 0.01f);
     void *din = to_dev(hin.data(), hin.size() * 2), *dw = to_dev(hw.data(), hw.size() * 2), *dsegs = to_dev(segs.data(), segs.size() * 8), *dbias = to_dev(bias.data(), bias.size() * 4);
-    void *dout, *dres; CK(hipMalloc(&dout, M * d.out_c * 2)); CK(hipMalloc(&dres, M * d.out_c * 2)); CK(hipMemset(dres, 0, M * d.out_c * 2));
+    const size_t out_elems = M * (size_t)d.out_c * d.rh * d.rw;
+    void *dout, *dres; CK(hipMalloc(&dout, out_elems * 2)); CK(hipMalloc(&dres, out_elems * 2)); CK(hipMemset(dres, 0, out_elems * 2)); CK(hipMemset(dout, 0xff, out_elems * 2));
     const size_t wsb = p_conv_ws(&d); void* dws; CK(hipMalloc(&dws, wsb ? wsb : 16));
-    auto run = [&] { return p_conv(&d, din, M * Ci * 2, dw, (const mv2_seg*)dsegs, (const float*)dbias, nullptr, residual ? dres : nullptr, dout, dws, wsb, st); };
+    auto run = [&] {
+        if (rms) return p_conv_rms(&d, din, M * Ci * 2, dw, (const mv2_seg*)dsegs, (const float*)dbias, residual ? dres : nullptr, dout, st);
+        return p_conv(&d, din, M * Ci * 2, dw, (const mv2_seg*)dsegs, (const float*)dbias, nullptr, residual ? dres : nullptr, dout, dws, wsb, st); };
     int rc = run(); CK(hipStreamSynchronize(st));
-    if (rc) { printf("   %s: mv2_conv rc=%d\n", name, rc); return; }
+    if (rc) { printf("   %s: mv2_conv rc=%d\n", name, rc); return -1.f; }
+    if (keep) { keep->resize(out_elems); CK(hipMemcpy(keep->data(), dout, out_elems * 2, hipMemcpyDeviceToHost)); }
     const float t = time_us(run, 20, st);
     const double gf = 2.0 * M * Ci * (double)Co * 1e-9;
     printf("== generic %-22s M=%zu Ci=%d Co=%d: %7.1f us (%5.0f TF/s)  split-K ws %.1f MB\n", name, M, Ci, Co, t, gf / t * 1e3, wsb / 1048576.0);
@@ -407,6 +416,26 @@ static void time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, in
         hipFree(dprof);
     }
     hipFree(din); hipFree(dw); hipFree(dsegs); hipFree(dbias); hipFree(dout); hipFree(dres); hipFree(dws);
+    return t;
+}
+
+// conv_pw_dma_kernel against conv_kernel on the same launch (experiments library: MV2_PW_DMA=0 switches the DMA kernel off, =N sets the tile
+// threshold): time of both + element-wise comparison of the two outputs (same MFMA order: bit-identical unless the row scale is fused)
+static void ab_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st, bool rms = false, int shuf = 1) {
+    std::vector<uint16_t> a, b;
+    setenv("MV2_PW_DMA", "0", 1);
+    const float t0 = time_pointwise(name, rows_t, rows_hw, Ci, Co, act, residual, st, rms, shuf, &a);
+    setenv("MV2_PW_DMA", "1", 1);
+    const float t1 = time_pointwise(name, rows_t, rows_hw, Ci, Co, act, residual, st, rms, shuf, &b);
+    unsetenv("MV2_PW_DMA");
+    size_t diff = 0, nan = 0; double maxd = 0;
+    for (size_t i = 0; i < a.size() && i < b.size(); ++i) {
+        const float x = bf2f(a[i]), y = bf2f(b[i]);
+        if (!(y == y)) ++nan;
+        if (a[i] != b[i]) { ++diff; maxd = std::max(maxd, (double)fabsf(x - y)); }
+    }
+    printf("## %-26s generic %6.1f us -> dma %6.1f us (%+5.1f %%)   differing elements %zu of %zu (max |d| %.3g, nan %zu)%s\n", name, t0, t1, (t1 / t0 - 1.f) * 100.f, diff, a.size(), maxd, nan,
+           a.size() != b.size() ? "  SIZE MISMATCH" : "");
 }
 
 int main(int argc, char** argv) {
@@ -418,6 +447,40 @@ int main(int argc, char** argv) {
     p_c3_tiles = (tiles_fn)dlsym(h, "mv2_conv3_tiles"); p_convpw = (convpw_fn)dlsym(h, "mv2_conv_pw");
     p_setprof = (setprof_fn)dlsym(h, "mv2_conv3_set_profile");
     if (!p_conv3 || !p_c3_ws || !p_c3_cnt || !p_c3_tiles) { printf("missing mv2_conv3 symbols\n"); return 2; }
+    if (argc > 2 && !strcmp(argv[2], "pwdma")) {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        p_conv_rms = (convrms_fn)dlsym(h, "mv2_conv_rms");
+        if (!p_conv_rms) { printf("no mv2_conv_rms\n"); return 2; }
+        // the pointwise launches of BASELINE configs[1] (B = 1) ...
+        ab_pointwise("ff1 C=256 T=20 geglu+rms", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 C=256 T=20 +res", 20, 32, 704, 256, MV2_ACT_NONE, true, st2);
+        ab_pointwise("ff1 C=512 T=20 geglu+rms", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 C=512 T=20 +res", 20, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        ab_pointwise("qkv C=512 T=20 rms", 20, 16, 512, 768, MV2_ACT_NONE, false, st2, true);
+        ab_pointwise("out C=512 T=20 +res", 20, 16, 256, 512, MV2_ACT_NONE, true, st2);
+        ab_pointwise("q C=256 T=20 rms", 20, 32, 256, 256, MV2_ACT_NONE, false, st2, true);
+        ab_pointwise("kv C=256 T=20 rms", 20, 32, 256, 512, MV2_ACT_NONE, false, st2, true);
+        ab_pointwise("out C=256 T=20 +res", 20, 32, 256, 256, MV2_ACT_NONE, true, st2);
+        ab_pointwise("up2x2 128->128 64x64 silu", 20, 64, 128, 512, MV2_ACT_SILU, false, st2, false, 2);
+        ab_pointwise("up2x2 256->128 32x32 silu", 20, 32, 256, 512, MV2_ACT_SILU, false, st2, false, 2);
+        ab_pointwise("up2x2 512->256 16x16 silu", 20, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 2);
+        ab_pointwise("ragged M=20x29x29 +res", 20, 29, 704, 256, MV2_ACT_NONE, true, st2);
+        // ... the deepest level (T = 5: 1280 rows, below the 128-tile threshold unless forced) ...
+        setenv("MV2_PW_DMA", "1", 1);
+        ab_pointwise("ff1 C=512 T=5 geglu+rms", 5, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 C=512 T=5 +res", 5, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        ab_pointwise("qkv C=512 T=5 rms", 5, 16, 512, 768, MV2_ACT_NONE, false, st2, true);
+        ab_pointwise("out C=512 T=5 +res", 5, 16, 256, 512, MV2_ACT_NONE, true, st2);
+        ab_pointwise("ff1 C=512 T=10 geglu+rms", 10, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 C=512 T=10 +res", 10, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        // ... and batch 4
+        ab_pointwise("ff1 B=4 C=512 geglu+rms", 80, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 B=4 C=512 +res", 80, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        ab_pointwise("ff1 B=4 C=256 geglu+rms", 80, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2, true);
+        ab_pointwise("ff2 B=4 C=256 +res", 80, 32, 704, 256, MV2_ACT_NONE, true, st2);
+        ab_pointwise("up2x2 128->128 B=4", 80, 64, 128, 512, MV2_ACT_SILU, false, st2, false, 2);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "generic")) {
         hipStream_t st2; CK(hipStreamCreate(&st2));
         p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
