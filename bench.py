@@ -215,7 +215,8 @@ def main():
     rows = per_launch_profile(tok, video, ops, tokenize_only)
     log('per-launch event profile done')
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
-    conv = [r for r in rows if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_out', 'mv2_conv3')]
+    # every launch that is MFMA GEMM work: the 3x3x3 kernel, the generic / LDS-DMA pointwise kernels, conv_in, conv_out, the ResidualUnit 1x1x1 + pooling
+    conv = [r for r in rows if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_in', 'mv2_conv_out', 'mv2_conv3', 'mv2_pw_se')]
     k3 = [r for r in rows if r['what'] == 'mv2_conv3']      # incl. the fused '.k3+k1' launches (their FLOPs include the 1x1x1)
     conv_ms, conv_flops = sum(r['ms'] for r in conv), sum(r['flops'] for r in conv)
     k3_ms, k3_flops = sum(r['ms'] for r in k3), sum(r['flops'] for r in k3)
