@@ -96,6 +96,41 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     assert lib.mv2_taylor_kv(0, ptr, ptr, 1, 4, 16, 8, None) == EINVAL                          # more chunks than tokens
 
 
+def test_launch_rules_of_the_library_match_their_restatement():
+    """The emulated plan must have the launches of the HIP plan, so the two launch rules the plan asks the library about
+    (mv2_conv_rms_ok, and through it which launches take the LDS-DMA pointwise kernel: mv2_conv_pointwise_dma) are restated in
+    oracle/ndhwc_ops.py (CpuOps.conv_rms_ok / _pw_dma).  Both are pure host functions of the descriptor: swept here without a GPU
+    (device_cus() falls back to 256, the value CpuOps assumes) over pointwise and gathered launches, both dtypes, every store / activation."""
+    import itertools
+    import random
+    from oracle.ndhwc_ops import CpuOps
+    lib, cpu = ops_hip.load_library(), CpuOps()
+    rnd = random.Random(7)
+    n = n_dma = n_rms = 0
+    shapes = [(1, 20, 16, 16), (1, 5, 16, 16), (1, 20, 32, 32), (4, 20, 32, 32), (1, 17, 64, 64), (1, 20, 29, 29), (2, 3, 8, 8), (1, 1, 4, 4), (1, 32, 16, 16)]
+    for (B, T, H, W), Ci, co, dtype, act, store in itertools.product(shapes, (64, 128, 256, 704, 1408, 96), (64, 128, 256, 768, 2816), (0, 1), (0, 1, 2, 3), (0, 1)):
+        if rnd.random() < 0.6:
+            continue
+        es = 2 if dtype == 0 else 4
+        if (Ci * es) % 128 or (act == 3 and store == 1):
+            continue
+        d = dict(dtype=dtype, B=B, Ti=T, Hi=H, Wi=W, Ci=Ci, To=T, Ho=H, Wo=W, co=co, co_pad=(co + 127) // 128 * 128, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
+                 kt=1, kh=1, kw=1, nsteps=Ci * es // 128, seg_bytes=128, check_bounds=0, act=act, store=store, rt=1, rh=2 if store == 1 else 1,
+                 rw=2 if store == 1 else 1, crop_t=0, out_c=co // 2 if act == 3 else (co // 4 if store == 1 else co), splitk=rnd.choice((0, 0, 0, 1, 2)))
+        variants = [d, dict(d, kh=3, kw=3, ph=1, pw=1, check_bounds=1, nsteps=9 * d['nsteps']), dict(d, seg_bytes=64), dict(d, To=(T + 1) // 2, st=2)]
+        for v in variants:
+            desc = ops_hip.ConvDesc(**v)
+            dma, rms = bool(lib.mv2_conv_pointwise_dma(ctypes.byref(desc))), bool(lib.mv2_conv_rms_ok(ctypes.byref(desc)))
+            assert cpu._pw_dma(v) == dma, v
+            assert cpu.conv_rms_ok(v) == rms, v
+            if dma:
+                assert v['dtype'] == 0 and v['kh'] == 1 and v['st'] == 1 and rms and lib.mv2_conv_workspace_bytes(ctypes.byref(desc)) == 0, v
+            n += 1
+            n_dma += dma
+            n_rms += rms
+    assert n > 1000 and n_dma > 50 and n_rms > n_dma and n_rms < n, (n, n_dma, n_rms)
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip('a GPU is present')
