@@ -3,14 +3,19 @@
 //
 // Why its own kernel: with N = 3 this is not MFMA work (3.4 GF per clip) but an HBM stream — 42 MB in, 3.3 MB out — and through the
 // generic gather kernel every input row is fetched once per TAP: 1280 workgroups x 27 steps x 36 KB = 1.24 GB through the L1s, 80 us
-// per clip on MI355X (9 % of the HBM roofline, profiles/r02).  Here a workgroup owns an 8 x 16 tile of ONE output frame: the kt input
-// frames of its 10 x 18 halo go to LDS once (4.2 x the tile bytes instead of 27 x), all taps are immediate offsets into that image.
+// per clip on MI355X (9 % of the HBM roofline, profiles/r02).  Round 3, first form: a workgroup owns an 8 x 16 tile of ONE output frame
+// and stages the kt input frames of its 10 x 18 halo in LDS (4.2 x the tile bytes instead of 27 x): 39 us — and purely fetch-bound: the 512
+// resident workgroups ask for 40 MB at once, 168 MB L2 -> LDS per launch.  This form: a workgroup WALKS a run of consecutive output frames
+// of its tile with a ring of three frame slots in LDS; every step fetches ONE new halo frame (requested before the step's MFMAs, written
+// after them into the slot that just died), so a run of n frames reads n + kt - 1 halo frames instead of kt n.
 //
 // MFMA shape: v_mfma_f32_16x16x32_bf16 with A = weights (rows = output channel, 3-4 of 16 used), B = 16 positions of one tile row;
-// a k-step is 32 of the 64 channels of one tap.  The four waves split the k-steps of a tile (K = kt * 9 * 2 = 54 steps; every wave keeps its
-// <= 14 weight fragments in registers for the whole launch: no LDS or L1 traffic for weights), and meet once per tile through LDS.
+// a k-step is 32 of the 64 channels of one tap.  The four waves split the k-steps of a frame (K = kt * 9 * 2 = 54 steps; every wave keeps its
+// <= 14 weight fragments in registers for the whole launch: no LDS or L1 traffic for weights), and meet once per frame through LDS.
 // Issue order per wave per k-step: 8 ds_read_b128 (the 8 tile rows) + 8 MFMAs.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/mv2.h"
 
@@ -21,18 +26,27 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int CO_TH = 8, CO_TW = 16;                      // output tile
 constexpr int CO_HW = CO_TW + 2, CO_HH = CO_TH + 2;       // halo 10 x 18
 constexpr int CO_PX = CO_HH * CO_HW;                      // 180 halo pixels per frame
-constexpr int CO_PITCH = 144;                             // bytes per halo pixel: 64 bf16 + 16 pad
-constexpr int CO_FRAME = ((CO_PX * CO_PITCH + 255) / 256) * 256;
+// LDS image of a halo frame: CHUNK-PLANAR, [8 chunks of 16 bytes (8 channels)][180 pixels] x 16 bytes, planes padded to a multiple of 256
+// bytes.  A B-operand read (lane l: position l % 16, channels 8 (l / 16) .. of the k-step) then takes 16 consecutive 16-byte pixels from
+// each of four equally aligned planes: free of bank conflicts under gfx950's REAL pass partition of ds_read_b128 (a pass is lanes {0-3,
+// 12-15, 20-27}, profiles/r03_findings.md section 8), which the pixel-major layout with a padded pitch cannot be (pitch 144: 2 passes extra
+// per read, and with eight waves per CU the LDS pipe, not the MFMAs, was the bound).  Writes: a quad of lanes (one write pass) holds four
+// consecutive pixels of one plane = 64 contiguous bytes.
+constexpr int CO_PLANE = ((CO_PX * 16 + 255) / 256) * 256;   // 3072
+constexpr int CO_FRAME = 8 * CO_PLANE;                    // 24576
 constexpr int CO_MAXKS = 14;                              // k-steps per wave: ceil(54 / 4)
+constexpr int CO_NB8 = (CO_PX + 7) / 8;                   // blocks of 8 pixels (= 1 KB of a contiguous row run, one wave-instruction) per frame
+constexpr int CO_NLD = (CO_NB8 * 64 + 255) / 256;         // chunks per thread and frame: 6
 
 struct ConvOutParams {
     const void* in; const void* wfrag; const float* bias; float* out;
     uint32_t in_bytes;
     int B, T, H, W, co, kt, crop_t, tiles_h, tiles_w;
+    int nseg;                                             // runs of consecutive output frames per tile (balanced split of the Tout frames)
 };
 
 __global__ __launch_bounds__(256, 2) void conv_out_kernel(const ConvOutParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];                  // three frame slots of CO_FRAME bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nks = p.kt * 18;                                                   // k-steps: tap-major, two channel halves per tap
@@ -43,8 +57,8 @@ __global__ __launch_bounds__(256, 2) void conv_out_kernel(const ConvOutParams p)
         const int ks = wave + 4 * i;
         wf[i] = ks < nks ? *(const i32x4*)((const char*)p.wfrag + ((size_t)ks * 64 + lane) * 16) : i32x4{0, 0, 0, 0};
     }
-    // ---- tile: blockIdx -> (b, output frame, tile row, tile col); XCD-aware: the eight XCDs take contiguous eighths of the list, so the
-    // workgroups that share halo frames (neighbouring tiles, consecutive frames) meet in one L2
+    // ---- blockIdx -> (b, run, tile row, tile col); XCD-aware: the eight XCDs take contiguous eighths of the list, so the workgroups that
+    // share halo pixels (neighbouring tiles, the frames where two runs of a tile overlap) meet in one L2
     const int Tout = p.T - p.crop_t;
     uint32_t bid = blockIdx.x;
     {
@@ -53,81 +67,119 @@ __global__ __launch_bounds__(256, 2) void conv_out_kernel(const ConvOutParams p)
     }
     const int twi = (int)(bid % (uint32_t)p.tiles_w); uint32_t rr = bid / (uint32_t)p.tiles_w;
     const int thi = (int)(rr % (uint32_t)p.tiles_h); rr /= (uint32_t)p.tiles_h;
-    const int to = (int)(rr % (uint32_t)Tout), b = (int)(rr / (uint32_t)Tout);
-    const int t = to + p.crop_t, h0 = thi * CO_TH, w0 = twi * CO_TW;
+    const int seg = (int)(rr % (uint32_t)p.nseg), b = (int)(rr / (uint32_t)p.nseg);
+    const int to0 = (int)(((int64_t)seg * Tout) / p.nseg), to1 = (int)(((int64_t)(seg + 1) * Tout) / p.nseg);
+    if (to0 >= to1) return;                                                      // (nseg <= Tout: never) whole workgroup, before any barrier
+    const int h0 = thi * CO_TH, w0 = twi * CO_TW;
 
-    // ---- halo: kt frames x 180 pixels x 8 chunks of 16 bytes, every load issued before the first wait
+    // ---- this thread's chunks of a halo frame: spatial source offset (out of range -> num_records: zeros, no traffic) and LDS offset;
+    // the frame enters as the scalar offset of the load
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    constexpr int NCH = CO_PX * 8;                                               // chunks per frame
-    constexpr int NLD = (3 * NCH + 255) / 256;                                   // 17 loads per thread at kt = 3
-    const int total = p.kt * NCH;
-    i32x4 hv[NLD];
+    uint32_t sp_off[CO_NLD], l_off[CO_NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + 256 * i;
-        uint32_t off = p.in_bytes;                                               // out of range -> zeros (padding, causal front, tail)
-        if (idx < total) {
-            const int fr = idx / NCH, rem = idx - fr * NCH;
-            const int px = rem >> 3, ch = rem & 7;
+    for (int i = 0; i < CO_NLD; ++i) {
+        // a wave-instruction covers 8 pixels x 8 chunks (eight whole 128-byte lines); lane l of it: chunk (l / 4) % 8, pixel 4 (l / 32) + l % 4
+        const int idx = tid + 256 * i, l = idx & 63;
+        const int px = (idx >> 6) * 8 + ((l >> 5) << 2) + (l & 3), ch = (l >> 2) & 7;
+        sp_off[i] = p.in_bytes; l_off[i] = 0xffffffffu;
+        if (px < CO_PX) {
             const int hy = px / CO_HW, hx = px - hy * CO_HW;
-            const int t_in = t + fr - (p.kt - 1), hin = h0 - 1 + hy, win = w0 - 1 + hx;
-            if (t_in >= 0 && (unsigned)hin < (unsigned)p.H && (unsigned)win < (unsigned)p.W)
-                off = (uint32_t)(((((int64_t)b * p.T + t_in) * p.H + hin) * p.W + win) * 128 + ch * 16);
+            const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
+            if ((unsigned)hin < (unsigned)p.H && (unsigned)win < (unsigned)p.W) sp_off[i] = (uint32_t)((hin * p.W + win) * 128 + ch * 16);
+            l_off[i] = (uint32_t)(ch * CO_PLANE + px * 16);
         }
-        hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0);
     }
+    const uint32_t frame_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
+    auto frame_loads = [&](int f, i32x4 (&v)[CO_NLD]) {                          // input frame f of clip b (f < 0: the causal zero frames)
+        const bool live = f >= 0;
+        const uint32_t so = live ? ((uint32_t)b * (uint32_t)p.T + (uint32_t)f) * frame_bytes : 0u;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < total) {
-            const int fr = idx / NCH, rem = idx - fr * NCH;
-            *(i32x4*)(smem + fr * CO_FRAME + (rem >> 3) * CO_PITCH + (rem & 7) * 16) = hv[i];
-        }
+        for (int i = 0; i < CO_NLD; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(live ? sp_off[i] : p.in_bytes), (int)so, 0);
+    };
+    auto frame_store = [&](int slot, const i32x4 (&v)[CO_NLD]) {
+#pragma unroll
+        for (int i = 0; i < CO_NLD; ++i)
+            if (l_off[i] != 0xffffffffu) *(i32x4*)(smem + slot * CO_FRAME + l_off[i]) = v[i];
+    };
+    auto slot_of = [](int f) { return (f + 3) % 3; };                            // f >= -2
+
+    // ---- prologue: the kt frames of the first output frame
+    {
+        const int t = to0 + p.crop_t;
+        i32x4 v0[CO_NLD], v1[CO_NLD], v2[CO_NLD];
+        frame_loads(t, v0);
+        if (p.kt > 1) frame_loads(t - 1, v1);
+        if (p.kt > 2) frame_loads(t - 2, v2);
+        frame_store(slot_of(t), v0);
+        if (p.kt > 1) frame_store(slot_of(t - 1), v1);
+        if (p.kt > 2) frame_store(slot_of(t - 2), v2);
     }
     __syncthreads();
 
-    // ---- taps.  B operand of tile row r, tap (it, ih, iw), half hf: lane l reads 16 bytes of pixel (r + ih, l % 16 + iw) at channel
-    // hf * 32 + 8 (l / 16): one per-lane base + compile-time offsets
-    f32x4_t acc[CO_TH];
+    const uint32_t lbase = (uint32_t)(lane >> 4) * CO_PLANE + (uint32_t)(lane & 15) * 16u;
+    const int64_t plane = (int64_t)p.H * p.W;
+    for (int to = to0; to < to1; ++to) {
+        const int t = to + p.crop_t;
+        const bool more = to + 1 < to1;
+        i32x4 nx[CO_NLD];
+        if (more) frame_loads(t + 1, nx);                                        // in flight under this frame's MFMAs
+        // ---- taps.  B operand of tile row r, tap (it, ih, iw), half hf: lane l reads 16 bytes of pixel (r + ih, l % 16 + iw) at channel
+        // hf * 32 + 8 (l / 16) = plane 4 hf + l / 16: one per-lane base + a wave-uniform offset
+        f32x4_t acc[CO_TH];
 #pragma unroll
-    for (int r = 0; r < CO_TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const uint32_t lbase = (uint32_t)(lane & 15) * CO_PITCH + (uint32_t)(lane >> 4) * 16u;
-#pragma unroll
-    for (int i = 0; i < CO_MAXKS; ++i) {
-        const int ks = wave + 4 * i;                                             // wave-uniform
-        if (ks < nks) {
+        for (int r = 0; r < CO_TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // fragment reads of k-step i + 1 are issued before the MFMAs of k-step i (two register sets): the LDS latency of a step hides under
+        // the previous step's eight MFMAs instead of in front of its own
+        i32x4 bf[2][CO_TH];
+        auto read_step = [&](int i, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            const int ks = wave + 4 * i;                                         // wave-uniform
             const int tap = ks >> 1, hf = ks & 1;
             const int it = tap / 9, ihw = tap - it * 9, ih = ihw / 3, iw = ihw - ih * 3;
-            const uint32_t o = lbase + (uint32_t)(it * CO_FRAME + (ih * CO_HW + iw) * CO_PITCH + hf * 64);
-            i32x4 bf[CO_TH];
+            const uint32_t o = lbase + (uint32_t)(slot_of(t + it - (p.kt - 1)) * CO_FRAME + hf * 4 * CO_PLANE + (ih * CO_HW + iw) * 16);
 #pragma unroll
-            for (int r = 0; r < CO_TH; ++r) bf[r] = *(const i32x4*)(smem + o + r * CO_HW * CO_PITCH);
+            for (int r = 0; r < CO_TH; ++r) bf[SET][r] = *(const i32x4*)(smem + o + r * CO_HW * 16);
+        };
+        read_step(0, std::integral_constant<int, 0>{});                          // nks >= 18: every wave has a first step
 #pragma unroll
-            for (int r = 0; r < CO_TH; ++r)
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, bf[r]), acc[r], 0, 0, 0);
+        for (int i = 0; i < CO_MAXKS; ++i) {
+            if (i + 1 < CO_MAXKS && wave + 4 * (i + 1) < nks) {
+                if (i & 1) read_step(i + 1, std::integral_constant<int, 0>{}); else read_step(i + 1, std::integral_constant<int, 1>{});
+            }
+            if (wave + 4 * i < nks) {
+#pragma unroll
+                for (int r = 0; r < CO_TH; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, bf[i & 1][r]), acc[r], 0, 0, 0);
+            }
         }
-    }
-    __syncthreads();                                                             // the halo is dead: LDS becomes the reduce buffer
+        __syncthreads();                    // every wave has read its taps: the slot of frame t + 1 (it held frame t - 2, or nothing) is free
 
-    // ---- cross-wave sum (fixed order) + bias, store.  D[co = 4 (l / 16) + i][pos = l % 16]: lanes 0..15 hold co 0..3 of their position
-    float* red = (float*)smem;                                                   // [wave][row][16 positions][4]
-    if (lane < 16) {
+        // ---- cross-wave sum (fixed order) + bias, store.  D[co = 4 (l / 16) + i][pos = l % 16]: lanes 0..15 hold co 0..3 of their position.
+        // The free slot is the exchange buffer first, the home of frame t + 1 afterwards
+        const int fslot = slot_of(t + 1);
+        float* red = (float*)(smem + fslot * CO_FRAME);                          // [wave][row][16 positions][4]
+        if (lane < 16) {
 #pragma unroll
-        for (int r = 0; r < CO_TH; ++r) *(f32x4_t*)(red + ((wave * CO_TH + r) * 16 + lane) * 4) = acc[r];
-    }
-    __syncthreads();
-    if (tid < CO_TH * CO_TW) {
-        const int r = tid >> 4, x = tid & 15;
-        f32x4_t s = *(const f32x4_t*)(red + (r * 16 + x) * 4);
+            for (int r = 0; r < CO_TH; ++r) *(f32x4_t*)(red + ((wave * CO_TH + r) * 16 + lane) * 4) = acc[r];
+        }
+        __syncthreads();
+        if (tid < CO_TH * CO_TW) {
+            const int r = tid >> 4, x = tid & 15;
+            f32x4_t s = *(const f32x4_t*)(red + (r * 16 + x) * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) { const f32x4_t v = *(const f32x4_t*)(red + ((w * CO_TH + r) * 16 + x) * 4); s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
-        const int h = h0 + r, w_ = w0 + x;
-        if (h < p.H && w_ < p.W) {
-            const int64_t plane = (int64_t)p.H * p.W;
-            float* dst = p.out + (((int64_t)b * p.co) * Tout + to) * plane + (int64_t)h * p.W + w_;
+            for (int w = 1; w < 4; ++w) { const f32x4_t v = *(const f32x4_t*)(red + ((w * CO_TH + r) * 16 + x) * 4); s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+            const int h = h0 + r, w_ = w0 + x;
+            if (h < p.H && w_ < p.W) {
+                float* dst = p.out + (((int64_t)b * p.co) * Tout + to) * plane + (int64_t)h * p.W + w_;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < p.co) dst[(int64_t)c * Tout * plane] = s[c] + (p.bias ? p.bias[c] : 0.f);
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.co) dst[(int64_t)c * Tout * plane] = s[c] + (p.bias ? p.bias[c] : 0.f);
+            }
+        }
+        if (more) {
+            __syncthreads();                // the partial sums have been read
+            frame_store(fslot, nx);
+            __syncthreads();
         }
     }
 }
@@ -155,7 +207,21 @@ extern "C" int mv2_conv_out(const mv2_conv_desc* d, const void* in, size_t in_by
     p.in = in; p.wfrag = wfrag; p.bias = bias; p.out = (float*)out; p.in_bytes = (uint32_t)in_bytes;
     p.B = d->B; p.T = d->Ti; p.H = d->Hi; p.W = d->Wi; p.co = d->co; p.kt = d->kt; p.crop_t = d->crop_t;
     p.tiles_h = (d->Hi + CO_TH - 1) / CO_TH; p.tiles_w = (d->Wi + CO_TW - 1) / CO_TW;
-    const int64_t blocks = (int64_t)d->B * (d->Ti - d->crop_t) * p.tiles_h * p.tiles_w;
+    // runs of output frames per tile: as long as possible (a run of n frames fetches n + kt - 1 halo frames) while the launch still has
+    // two workgroups per CU to overlap fetch and MFMA
+    const int Tout = d->Ti - d->crop_t;
+    const int64_t tiles = (int64_t)d->B * p.tiles_h * p.tiles_w;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    int per_cu = 2;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_CONVOUT_WG")) per_cu = atoi(e) > 0 ? atoi(e) : 2;            // workgroups per CU the run split aims at
+#endif
+    int64_t nseg = (per_cu * (int64_t)cus + tiles - 1) / tiles;
+    if (nseg > Tout) nseg = Tout;
+    if (nseg < 1) nseg = 1;
+    p.nseg = (int)nseg;
+    const int64_t blocks = tiles * p.nseg;
     if (blocks <= 0 || blocks >= (int64_t)0x7fffffff) return MV2_ETOOLARGE;
     const int lds = 3 * CO_FRAME;
     if (hipFuncSetAttribute((const void*)conv_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MV2_ENODEVICE;

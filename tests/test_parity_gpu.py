@@ -410,11 +410,12 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
 
 
-@pytest.mark.parametrize('case', ['rows_residual', 'geglu_rms', 'shuffle_silu', 'long_k_residual', 'edge_256_rms', 'below_threshold'])
+@pytest.mark.parametrize('case', ['rows_residual', 'geglu_rms', 'shuffle_silu', 'long_k_residual', 'edge_256_rms', 'rows_rowscale_lrelu', 'below_threshold'])
 def test_pointwise_dma_kernel_vs_emulation(case):
     """conv_pw_dma_kernel (conv.hip: both GEMM operands global -> LDS by buffer_load ... lds, hand-placed waits) behind mv2_conv /
     mv2_conv_rms against the emulation: plain rows + residual with a ragged last tile, GEGLU with the RMSNorm row scale computed in the
-    launch, depth-to-space store + SiLU (the up-sampling conv), a 22-step K loop, exactly 256 tiles (the threshold) with the row scale;
+    launch, depth-to-space store + SiLU (the up-sampling conv), a 22-step K loop, exactly 256 tiles (the threshold) with the row scale, a
+    caller-supplied row scale + residual + leaky ReLU on a ragged launch (the AdaptiveRMSNorm / discriminator forms);
     the last case has 160 tiles and stays on conv_kernel (the rule is checked on both sides: library and its restatement)."""
     from magvit2_pytorch_amd import pack as PK
     from magvit2_pytorch_amd.ops_hip import HipOps
@@ -426,12 +427,15 @@ def test_pointwise_dma_kernel_vs_emulation(case):
         'shuffle_silu': (17, 32, 32, 128, 512, PK.ACT_SILU, PK.STORE_SHUFFLE, (1, 2, 2), False, False, True),    # 136 x 4 tiles, 2 steps
         'long_k_residual': (32, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, True),    # 64 x 4 = 256 tiles, 22 steps
         'edge_256_rms': (16, 32, 32, 640, 256, PK.ACT_ELU, PK.STORE_ROWS, (1, 1, 1), False, True, True),         # 128 x 2 = 256 tiles, 10 steps
+        'rows_rowscale_lrelu': (5, 60, 60, 192, 256, PK.ACT_LRELU, PK.STORE_ROWS, (1, 1, 1), True, 'given', True),  # 141 x 2 tiles, ragged; the caller's row scale
         'below_threshold': (20, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, False),   # 40 x 4 = 160 tiles: conv_kernel
     }[case]
     M = T * H * W
     w2d = torch.randn(co_ref, Ci, generator=g) / Ci ** 0.5
     bias = torch.randn(co_ref, generator=g) * 0.1
-    gamma = torch.full((Ci,), float(Ci) ** 0.5) if rms else None      # RMSNorm's gamma * sqrt(dim), folded into the weights as the plan does
+    gamma = torch.full((Ci,), float(Ci) ** 0.5) if rms is True else None      # RMSNorm's gamma * sqrt(dim), folded into the weights as the plan does
+    given = rms == 'given'            # the caller passes a row scale (AdaptiveRMSNorm / mv2_rms_rowscale path): mv2_conv, not mv2_conv_rms
+    rms = rms is True
     if act == PK.ACT_GEGLU:
         pc, hidden = PK.pack_geglu_in(w2d, bias, torch.bfloat16, in_scale=gamma)
         out_c = hidden
@@ -462,8 +466,9 @@ def test_pointwise_dma_kernel_vs_emulation(case):
         cpu.conv_rms(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, r, out_c_)(None)
         ops.conv_rms(d, xg, x.numel() * 2, wg, segs_g, bg, rg, out_g)(ops.current_stream())
     else:
-        cpu.conv(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, None, r, out_c_, None)(None)
-        ops.conv(d, xg, x.numel() * 2, wg, segs_g, bg, None, rg, out_g, None)(ops.current_stream())
+        rs = (torch.rand(M, generator=g) + 0.5) if given else None
+        cpu.conv(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, rs, r, out_c_, None)(None)
+        ops.conv(d, xg, x.numel() * 2, wg, segs_g, bg, None if rs is None else rs.to(dev), rg, out_g, None)(ops.current_stream())
     ops.synchronize()
     a, b = out_g.cpu().float(), out_c_.float()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
@@ -505,10 +510,11 @@ def test_conv_in_kernel_vs_emulation(B, T, H, W, ci, kt):
 
 
 @pytest.mark.parametrize('B,T,H,W,co,kt,crop', [(1, 20, 128, 128, 3, 3, 3), (2, 5, 20, 36, 3, 3, 0), (1, 3, 9, 17, 4, 3, 2), (3, 1, 16, 16, 1, 1, 0),
-                                                 (1, 4, 8, 16, 3, 2, 1)])
+                                                 (1, 4, 8, 16, 3, 2, 1), (8, 6, 64, 64, 3, 2, 1), (16, 4, 32, 64, 2, 1, 0), (4, 20, 128, 128, 3, 3, 3)])
 def test_conv_out_kernel_vs_emulation(B, T, H, W, co, kt, crop):
     """mv2_conv_out (convout.hip: halo frames staged once, 16x16x32 MFMA, k-steps split over the waves) against the dense
-    convolution the emulation runs from the same fragment image: ragged tiles, kt 1..3, 1..4 output channels, cropped front frames."""
+    convolution the emulation runs from the same fragment image: ragged tiles, kt 1..3, 1..4 output channels, cropped front frames; runs of
+    1 / 2 / 3 / 4-5 / 17 consecutive output frames per workgroup (the frame ring in LDS) at every kt."""
     from magvit2_pytorch_amd import pack as PK
     from magvit2_pytorch_amd.ops_hip import HipOps
     ops, cpu = HipOps('cuda:0'), CpuOps()
