@@ -52,7 +52,8 @@ template <int TH, int TW> struct Geo {
 };
 
 // weight image: [chunk][tap 9][co tile of 32 (Co / 32)][k-slice 4][64 lanes][16 B]: lane l of (tap, ct, ks) holds w[co = 32 ct + l % 32][tap][ci = 64 chunk + 16 ks + 8 (l / 32) .. + 8)
-template <int TH, int TW>
+// ABL (timing only, wrong results): 1 = no weight loads (fragments stay what tap 0 loaded), 2 = no halo loads after the first slab
+template <int TH, int TW, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
     typedef Geo<TH, TW> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
     // nine taps per slab: the register set of a slab's first tap alternates from slab to slab (PAR), so the slab loop is unrolled by two
     auto slab = [&](int chunk, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
-        slab_loads(chunk + 1, hv);                                 // next slab under this slab's taps (past the end: out of range, zeros, no traffic)
+        if (ABL != 2) slab_loads(chunk + 1, hv);                   // next slab under this slab's taps (past the end: out of range, zeros, no traffic)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ih = tap / 3, iw = tap - ih * 3;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) wf[(tap + 1 + PAR) & 1][ks][a] = wfrag(nchunk_, ntap, ks, a);
+                for (int a = 0; a < 2; ++a) wf[(tap + 1 + PAR) & 1][ks][a] = ABL == 1 ? wf[(tap + PAR) & 1][ks][a] : wfrag(nchunk_, ntap, ks, a);
             const uint32_t o = (iw == 1 ? b_odd + (uint32_t)(ih * G::RO * PITCH) : b_even + (uint32_t)((ih * G::RE + (iw >> 1)) * PITCH));
             i32x4 bf[4];
 #pragma unroll
@@ -186,7 +187,7 @@ static inline float frand() { rng = rng * 1664525u + 1013904223u; return ((rng >
 static inline uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static inline float h_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int TH, int TW>
+template <int TH, int TW, int ABL = 0>
 static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
     typedef Geo<TH, TW> G;
     const int Wi = Hi, Ho = Hi / 2, Wo = Wi / 2, nchunk = Ci / 64;
@@ -208,8 +209,8 @@ static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
     CK(hipMemset(dout, 0xff, out.size() * 2));
     P p{dx, dw, dout, (uint32_t)(x.size() * 2), F, Hi, Wi, Ci, Co, Ho, Wo, (Ho + TH - 1) / TH, (Wo + TW - 1) / TW, nchunk};
     const int blocks = F * p.tiles_h * p.tiles_w * (Co / 128);
-    CK(hipFuncSetAttribute((const void*)ds2_kernel<TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-    hipLaunchKernelGGL((ds2_kernel<TH, TW>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    CK(hipFuncSetAttribute((const void*)ds2_kernel<TH, TW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
     int bad = 0; double maxd = 0;
@@ -231,13 +232,13 @@ static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
         if (d > 0.03 + 0.01 * fabs(ref)) ++bad;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1000.0 / reps;
-    printf("%-34s tile %dx%-2d F=%-3d %3dx%-3d Ci=%-3d Co=%-3d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, TH, TW, F, Hi, Wi, Ci, Co, us,
+    printf("%-34s%s tile %dx%-2d F=%-3d %3dx%-3d Ci=%-3d Co=%-3d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, ABL == 1 ? " [no weight loads]" : (ABL == 2 ? " [no halo reloads]" : ""), TH, TW, F, Hi, Wi, Ci, Co, us,
            2.0 * F * Ho * Wo * Co * 9.0 * Ci / us / 1e6, maxd, bad, blocks, G::LDS / 1024);
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dout));
 }
@@ -252,5 +253,12 @@ int main() {
     run<2, 32>("enc.1 B=4", 80, 128, 64, 128, 10);
     run<4, 16>("enc.3 B=4", 80, 64, 128, 256, 10);
     run<4, 16>("enc.6 B=4", 80, 32, 256, 512, 10);
+    // timing-only ablations: what bounds the prototype?
+    run<4, 16, 1>("enc.1", 20, 128, 64, 128, 30);
+    run<4, 16, 1>("enc.3", 20, 64, 128, 256, 30);
+    run<4, 16, 1>("enc.6", 20, 32, 256, 512, 30);
+    run<4, 16, 2>("enc.3", 20, 64, 128, 256, 30);
+    run<4, 16, 2>("enc.6", 20, 32, 256, 512, 30);
+    run<4, 16, 1>("enc.3 B=4", 80, 64, 128, 256, 10);
     return 0;
 }
