@@ -53,7 +53,7 @@ template <int TH, int TW> struct Geo {
 
 // weight image: [chunk][tap 9][co tile of 32 (Co / 32)][k-slice 4][64 lanes][16 B]: lane l of (tap, ct, ks) holds w[co = 32 ct + l % 32][tap][ci = 64 chunk + 16 ks + 8 (l / 32) .. + 8)
 // ABL (timing only, wrong results): 1 = no weight loads (fragments stay what tap 0 loaded), 2 = no halo loads after the first slab
-template <int TH, int TW, int ABL = 0>
+template <int TH, int TW, int ABL = 0, int WD = 1>
 __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
     typedef Geo<TH, TW> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -119,11 +119,11 @@ __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
 
     i32x4 hv[G::NLD];
     slab_loads(0, hv);
-    i32x4 wf[2][4][2];                                             // [set][k-slice][co tile]
+    i32x4 wf[WD + 1][4][2];                                        // [set][k-slice][co tile]; WD = taps of prefetch distance (WD = 2: three sets, 9 taps per slab keep the set of tap t at t % 3)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) wf[0][ks][a] = wfrag(0, 0, ks, a);
+        for (int a = 0; a < 2; ++a) { wf[0][ks][a] = wfrag(0, 0, ks, a); if constexpr (WD == 2) wf[1][ks][a] = wfrag(0, 1, ks, a); }
     slab_store(hv);
     __syncthreads();
 
@@ -134,12 +134,14 @@ __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ih = tap / 3, iw = tap - ih * 3;
-            // next tap's weights (next slab's tap 0 behind tap 8; behind the last slab: a harmless re-read of slab 0)
-            const int ntap = tap == 8 ? 0 : tap + 1, nchunk_ = tap == 8 ? (chunk + 1 < p.nchunk ? chunk + 1 : 0) : chunk;
+            // the weights WD taps ahead (the next slab's first taps behind tap 8 / 7; behind the last slab: a harmless re-read of slab 0)
+            const int nt_ = tap + WD, ntap = nt_ >= 9 ? nt_ - 9 : nt_, nchunk_ = nt_ >= 9 ? (chunk + 1 < p.nchunk ? chunk + 1 : 0) : chunk;
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int wset = WD == 2 ? (tap + 2) % 3 : (tap + 1 + PAR) & 1, rset = WD == 2 ? tap % 3 : (tap + PAR) & 1;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) wf[(tap + 1 + PAR) & 1][ks][a] = ABL == 1 ? wf[(tap + PAR) & 1][ks][a] : wfrag(nchunk_, ntap, ks, a);
+                for (int a = 0; a < 2; ++a) wf[wset][ks][a] = ABL == 1 ? wf[rset][ks][a] : wfrag(nchunk_, ntap, ks, a);
             const uint32_t o = (iw == 1 ? b_odd + (uint32_t)(ih * G::RO * PITCH) : b_even + (uint32_t)((ih * G::RE + (iw >> 1)) * PITCH));
             i32x4 bf[4];
 #pragma unroll
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void ds2_kernel(const P p) {
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[(tap + PAR) & 1][ks][a]), __builtin_bit_cast(bf16x8, bf[ks]), acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[rset][ks][a]), __builtin_bit_cast(bf16x8, bf[ks]), acc[a], 0, 0, 0);
         }
         __syncthreads();                                           // every wave has read the slab
         if (chunk + 1 < p.nchunk) {
@@ -187,7 +189,7 @@ static inline float frand() { rng = rng * 1664525u + 1013904223u; return ((rng >
 static inline uint16_t h_f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static inline float h_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int TH, int TW, int ABL = 0>
+template <int TH, int TW, int ABL = 0, int WD = 1>
 static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
     typedef Geo<TH, TW> G;
     const int Wi = Hi, Ho = Hi / 2, Wo = Wi / 2, nchunk = Ci / 64;
@@ -209,8 +211,8 @@ static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
     CK(hipMemset(dout, 0xff, out.size() * 2));
     P p{dx, dw, dout, (uint32_t)(x.size() * 2), F, Hi, Wi, Ci, Co, Ho, Wo, (Ho + TH - 1) / TH, (Wo + TW - 1) / TW, nchunk};
     const int blocks = F * p.tiles_h * p.tiles_w * (Co / 128);
-    CK(hipFuncSetAttribute((const void*)ds2_kernel<TH, TW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-    hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    CK(hipFuncSetAttribute((const void*)ds2_kernel<TH, TW, ABL, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL, WD>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
     int bad = 0; double maxd = 0;
@@ -232,13 +234,13 @@ static void run(const char* name, int F, int Hi, int Ci, int Co, int reps) {
         if (d > 0.03 + 0.01 * fabs(ref)) ++bad;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL, WD>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL>), dim3(blocks), dim3(256), G::LDS, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ds2_kernel<TH, TW, ABL, WD>), dim3(blocks), dim3(256), G::LDS, 0, p);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1000.0 / reps;
-    printf("%-34s%s tile %dx%-2d F=%-3d %3dx%-3d Ci=%-3d Co=%-3d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, ABL == 1 ? " [no weight loads]" : (ABL == 2 ? " [no halo reloads]" : ""), TH, TW, F, Hi, Wi, Ci, Co, us,
+    printf("%-34s%s tile %dx%-2d F=%-3d %3dx%-3d Ci=%-3d Co=%-3d  %7.1f us  %6.0f TF/s  max|d| %.3e bad %d  (%d blocks, %d KB LDS)\n", name, ABL == 1 ? " [no weight loads]" : (ABL == 2 ? " [no halo reloads]" : (WD == 2 ? " [weights 2 taps ahead]" : "")), TH, TW, F, Hi, Wi, Ci, Co, us,
            2.0 * F * Ho * Wo * Co * 9.0 * Ci / us / 1e6, maxd, bad, blocks, G::LDS / 1024);
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dout));
 }
@@ -253,6 +255,10 @@ int main() {
     run<2, 32>("enc.1 B=4", 80, 128, 64, 128, 10);
     run<4, 16>("enc.3 B=4", 80, 64, 128, 256, 10);
     run<4, 16>("enc.6 B=4", 80, 32, 256, 512, 10);
+    run<4, 16, 0, 2>("enc.1", 20, 128, 64, 128, 30);
+    run<4, 16, 0, 2>("enc.3", 20, 64, 128, 256, 30);
+    run<4, 16, 0, 2>("enc.6", 20, 32, 256, 512, 30);
+    run<4, 16, 0, 2>("enc.3 B=4", 80, 64, 128, 256, 10);
     // timing-only ablations: what bounds the prototype?
     run<4, 16, 1>("enc.1", 20, 128, 64, 128, 30);
     run<4, 16, 1>("enc.3", 20, 64, 128, 256, 30);
