@@ -18,11 +18,11 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmv2_hip.so')
 # product library: no environment switches, no experimental kernels
-SOURCES = ['conv.hip', 'conv3.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
+SOURCES = ['conv.hip', 'conv3.hip', 'conv3p.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
 # experiments library (tools/ only, -DMV2_EXPERIMENTS): the same sources with phase-clock profiling and the conv3 work-split knobs
 LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
 SOURCES_EXP = SOURCES
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'),
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv3p.h'),
            os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 

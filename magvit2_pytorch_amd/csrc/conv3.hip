@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "conv_common.h"
+#include "conv3p.h"
 
 namespace {
 
@@ -965,6 +966,15 @@ extern "C" int mv2_conv3_set_profile(void* device_buffer) {      // experiments 
 }
 #endif
 
+// Which kernel serves a launch: the position-tile kernel of conv3p.hip takes every bf16 shape, this file's K-split kernel the exact-fp32
+// mode.  A pure function of the descriptor (the experiments library lets tools/k3_bench force either: MV2_C3_KERNEL=old|new).
+static bool use_conv3p(const mv2_conv_desc& d) {
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3_KERNEL")) return e[0] == 'n' && conv3p_eligible(d);
+#endif
+    return conv3p_eligible(d);
+}
+
 extern "C" int mv2_conv3_eligible(const mv2_conv_desc* d) { return d && eligible3(*d) ? 1 : 0; }
 
 extern "C" int mv2_conv3_fusable(const mv2_conv_desc* d) {
@@ -973,7 +983,11 @@ extern "C" int mv2_conv3_fusable(const mv2_conv_desc* d) {
 
 extern "C" size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d) {
     if (!d || !eligible3(*d)) return 0;
-    return plan3(*d).slab_bytes;
+#ifdef MV2_EXPERIMENTS
+    return std::max(plan3(*d).slab_bytes, conv3p_eligible(*d) ? conv3p_workspace_bytes(*d) : (size_t)0);      // the harness switches kernels between calls
+#else
+    return use_conv3p(*d) ? conv3p_workspace_bytes(*d) : plan3(*d).slab_bytes;
+#endif
 }
 
 extern "C" size_t mv2_conv3_counter_bytes(const mv2_conv_desc* d) {
@@ -1004,6 +1018,9 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
         if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU) return MV2_EINVAL;
     } else if (bias2 || se_part) return MV2_EINVAL;
     if (se_part && !se_wk) return MV2_EINVAL;
+    if (use_conv3p(*d))
+        return conv3p_launch(d, in, in_bytes, wp3, bias, wp2, bias2, act2, se_wk, se_bk, se_part, out, workspace, workspace_bytes, counters, counter_bytes,
+                             (hipStream_t)stream);
     if (P.slab_bytes > 0 && (!workspace || workspace_bytes < P.slab_bytes)) return MV2_EWORKSPACE;
     if (P.workers > 1 && (!counters || counter_bytes < (size_t)P.n_tiles * sizeof(uint32_t))) return MV2_EWORKSPACE;
     ConvParams p{};

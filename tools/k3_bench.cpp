@@ -27,7 +27,8 @@ typedef int (*convpw_fn)(const mv2_conv_desc*, const void*, size_t, const void*,
 typedef int (*tiles_fn)(const mv2_conv_desc*, int*, int*);
 
 typedef int (*setprof_fn)(void*);
-static setprof_fn p_setprof;
+static setprof_fn p_setprof, p_setprof_old, p_setprof_new;
+static int set_both_profiles(void* b) { int r = 0; if (p_setprof_old) r |= p_setprof_old(b); if (p_setprof_new) r |= p_setprof_new(b); return r; }   // conv3.hip (K-split) and conv3p.hip (position tile) write the same record layout
 static conv_fn p_conv; static ws_fn p_conv_ws, p_c3_ws, p_c3_cnt; static elig_fn p_c3_fusable; static conv3_fn p_conv3; static convpw_fn p_convpw; static tiles_fn p_c3_tiles;
 
 static uint32_t rng_state = 12345u;
@@ -445,7 +446,9 @@ int main(int argc, char** argv) {
     p_conv = (conv_fn)dlsym(h, "mv2_conv"); p_conv_ws = (ws_fn)dlsym(h, "mv2_conv_workspace_bytes");
     p_conv3 = (conv3_fn)dlsym(h, "mv2_conv3"); p_c3_ws = (ws_fn)dlsym(h, "mv2_conv3_workspace_bytes"); p_c3_cnt = (ws_fn)dlsym(h, "mv2_conv3_counter_bytes"); p_c3_fusable = (elig_fn)dlsym(h, "mv2_conv3_fusable");
     p_c3_tiles = (tiles_fn)dlsym(h, "mv2_conv3_tiles"); p_convpw = (convpw_fn)dlsym(h, "mv2_conv_pw");
-    p_setprof = (setprof_fn)dlsym(h, "mv2_conv3_set_profile");
+    p_setprof_old = (setprof_fn)dlsym(h, "mv2_conv3_set_profile"); p_setprof_new = (setprof_fn)dlsym(h, "mv2_conv3p_set_profile");
+    if (p_setprof_old || p_setprof_new) p_setprof = set_both_profiles;
+    printf("conv3 kernel under test: MV2_C3_KERNEL=%s\n", getenv("MV2_C3_KERNEL") ? getenv("MV2_C3_KERNEL") : "(library rule)");
     if (!p_conv3 || !p_c3_ws || !p_c3_cnt || !p_c3_tiles) { printf("missing mv2_conv3 symbols\n"); return 2; }
     if (argc > 2 && !strcmp(argv[2], "pwdma")) {
         hipStream_t st2; CK(hipStreamCreate(&st2));
