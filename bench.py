@@ -21,16 +21,21 @@ Timing: W warm-up steps, then a >= 1 s untimed soak at full load (a fresh box ne
 reported as `soak_steps`), then EXACTLY K steps between barrier + synchronize pairs, max over ranks.
 
 Extra objects on the JSON line:
-  roofline       — the dominant kernel (conv3_kernel = the ResidualUnit k x 3 x 3 causal convs, 81 % of the path's FLOPs).
+  roofline       — the dominant kernel (mv2_conv3 = the ResidualUnit k x 3 x 3 causal convs, 81 % of the path's FLOPs).
                    achieved = sum of ALGORITHMIC flops (2*M*Cout*K, un-padded) of those launches of one step / sum of their
-                   durations, each measured live with HIP events on the launch stream.  traffic: HBM-side bytes per launch
-                   from the committed rocprofv3 PMC passes (`traffic_source` names the file; null when none applies).
+                   durations, each measured live with HIP events on the launch stream; frac_executed = the same with the flops the
+                   kernel executes (it skips the time taps in the causal zero padding, which the reference multiplies).  traffic:
+                   HBM-side bytes per launch from the committed rocprofv3 PMC passes (`traffic_source` names the file; null when none applies).
+  batch4         — (N = 1, configs[1]) the per-GPU shape of configs[2], 4 clips per step, timed in the same process: ms/step,
+                   frames/s and the conv3 fraction at that shape.
   exact_fp32_mode— (N = 1, configs[1]) throughput and id mismatch of the bit-exact mode (fp32 storage + fp32 MFMA).
-  cpu_baseline   — the CPU oracle (oracle/restate.py, torch fp32; kind "port": /root/reference does not exist on the GPU box) timed on this
-                   box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).  `cores` = the thread count of the
+  cpu_baseline   — kind "reference": the reference's own VideoTokenizer.forward (build-time copy oracle/_ref, loaded by oracle/ref_loader.py)
+                   timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only); kind "port"
+                   (oracle/restate.py, torch fp32) where that copy is absent; with the copy the port's figure is kept as `port_value`.  `cores` = the thread count of the
                    timed runs, chosen by the printed thread sweep (small sample, ascending, cut at 3x the best) up to `cores_available`; plus its
                    bf16-autocast drift (one draw of the tolerance yardstick; the six-seed yardstick of the tests comes from the
                    real reference, tests/golden/bf16_yardstick.json).
+  rccl_ranks / per_rank_ms_per_step — (N > 1) torch.distributed world size and every rank's own ms/step (all_gather over RCCL).
   roofline.encode_path — MFMA and HBM fractions of the encoder launches alone (the path north_star names), same event table.
 """
 from __future__ import annotations
@@ -66,6 +71,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='skip the exact-fp32-mode leg')
     ap.add_argument('--no-soak', action='store_true')
+    ap.add_argument('--no-batch4', action='store_true', help='skip the configs[2] per-GPU-shape leg of the N = 1 line')
     ap.add_argument('--breakdown', default='', help='write the per-launch timing table to this json file')
     return ap.parse_args()
 
@@ -90,7 +96,7 @@ def kernel_source_hash():
     """sha256 over the conv3 kernel sources: what profiles/r03_traffic.json is stamped with (tools/pmc_aggregate.py)"""
     import hashlib
     h = hashlib.sha256()
-    for fn in ('conv3.hip', 'conv_common.h', 'common.h'):
+    for fn in ('conv3.hip', 'conv3p.hip', 'conv3p.h', 'conv_common.h', 'common.h'):
         with open(os.path.join(ROOT, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
@@ -122,7 +128,8 @@ def per_launch_profile(tok, video, ops, tokenize_only=False):
     for i, st in enumerate(steps):
         ms = lib.mv2_event_elapsed_ms(evs[i], evs[i + 1]) / REPS
         rows.append(dict(i=i, what=getattr(st, 'what', '?'), label=getattr(st, 'label', getattr(st, 'what', '?')),
-                         ms=ms, flops=plan.step_flops.get(id(st), 0.0)))
+                         ms=ms, flops=plan.step_flops.get(id(st), 0.0),
+                         flops_exec=plan.step_flops_exec.get(id(st), plan.step_flops.get(id(st), 0.0))))
     for e in evs:
         lib.mv2_event_destroy(e)
     return rows
@@ -193,7 +200,14 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
+    rank_ms, rccl_ranks = None, None
     if world > 1:
+        # evidence for the scaling record: every rank's own time (all_gather over RCCL) next to the max the value is computed from
+        mine = torch.tensor([el], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allt, mine)
+        rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in allt]
+        rccl_ranks = torch.distributed.get_world_size()
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
@@ -220,21 +234,23 @@ def main():
     k3 = [r for r in rows if r['what'] == 'mv2_conv3']      # incl. the fused '.k3+k1' launches (their FLOPs include the 1x1x1)
     conv_ms, conv_flops = sum(r['ms'] for r in conv), sum(r['flops'] for r in conv)
     k3_ms, k3_flops = sum(r['ms'] for r in k3), sum(r['flops'] for r in k3)
+    k3_flops_exec = sum(r['flops_exec'] for r in k3)
     all_ms = sum(r['ms'] for r in rows)
     achieved = k3_flops / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
+    achieved_exec = k3_flops_exec / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
     all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # HBM-side bytes per conv3 launch: from the committed rocprofv3 --pmc passes of THIS command (not collectable in-process).  The file is
     # stamped with a hash of the kernel sources it was measured on; a stale file is not printed.
     traffic, traffic_source = None, None
-    tf = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+    tf = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
     if os.path.exists(tf) and args.dtype == 'bf16' and B == 1 and cfg_id == 1:
         try:
             js = json.load(open(tf))
             if js.get('kernel_source_sha256') == kernel_source_hash():
                 traffic = js.get('conv3_kernel_hbm_bytes_per_launch')
-                traffic_source = 'profiles/r03_traffic.json (rocprofv3 --pmc passes of this command on these kernel sources: tools/gpu_profile.sh)'
+                traffic_source = 'profiles/r04_traffic.json (rocprofv3 --pmc passes of this command on these kernel sources: tools/gpu_profile.sh)'
             else:
-                traffic_source = 'profiles/r03_traffic.json is stale (measured on other kernel sources): not printed'
+                traffic_source = 'profiles/r04_traffic.json is stale (measured on other kernel sources): not printed'
         except Exception:
             traffic = None
     # encode path alone (north_star names it): MFMA and HBM fractions from the same event table; algorithmic bytes per SURVEY.md §8(d)
@@ -246,11 +262,14 @@ def main():
                        mfma_frac=round(enc_flops / (enc_ms * 1e-3) / 1e12 / peak, 4) if enc_ms > 0 else None,
                        hbm_frac=round(enc_bytes / (enc_ms * 1e-3) / 6.3e12, 4) if (enc_bytes and enc_ms > 0) else None,
                        algorithmic_bytes=enc_bytes, hbm_peak='6.3 TB/s achievable (8.0 spec)')
-    roofline = dict(bound='mfma', kernel='conv3_kernel (ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
-                    achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
+    roofline = dict(bound='mfma', kernel='conv3p_kernel (mv2_conv3: ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
+                    achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4),
+                    # frac counts ALGORITHMIC flops (2*M*Cout*K: the reference multiplies the causal zero padding); frac_executed
+                    # counts what the matrix pipe executes (the kernel skips the taps in the causal front: 5 / 10 / 20 % at T = 20 / 10 / 5)
+                    achieved_executed=round(achieved_exec, 2), frac_executed=round(achieved_exec / peak, 4), traffic=traffic,
                     traffic_source=traffic_source, launches=len(k3), flops_per_launch=k3_flops / max(len(k3), 1),
                     avg_launch_ms=round(k3_ms / max(len(k3), 1), 5),
-                    avg_launch_authority='profiles/r03_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
+                    avg_launch_authority='profiles/r04_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
                                          'the in-process figure issues every launch 5x back to back between two HIP events (L2/MALL-warm repeats)',
                     encode_path=encode_path,
                     all_conv_launches=dict(launches=len(conv), flops_per_step=conv_flops, ms_per_step=round(conv_ms, 4),
@@ -263,6 +282,34 @@ def main():
             a = agg.setdefault(r['label'] if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_out', 'mv2_conv3') else r['what'], dict(ms=0.0, flops=0.0, n=0))
             a['ms'] += r['ms']; a['flops'] += r['flops']; a['n'] += 1
         json.dump(dict(rows=rows, by_label=agg), open(args.breakdown, 'w'), indent=1)
+
+    # ---- configs[2]'s per-GPU shape (4 clips per step) on the same line: the multi-GPU runs use this shape per rank, and a skipped
+    # SCALE record leaves it without driver-timed evidence otherwise
+    batch4 = None
+    if world == 1 and cfg_id == 1 and args.dtype == 'bf16' and not args.no_batch4:
+        v4 = torch.randn(4, 3, T, 128, 128, generator=torch.Generator().manual_seed(7)).to(dev)
+        for _ in range(4):
+            tok(v4, return_codes=True, return_recon=True)
+        torch.cuda.synchronize(dev)
+        n4 = max(20, min(args.steps, 100))
+        t1 = time.perf_counter()
+        for _ in range(n4):
+            c4, r4 = tok(v4, return_codes=True, return_recon=True)
+        torch.cuda.synchronize(dev)
+        e4 = time.perf_counter() - t1
+        rows4 = per_launch_profile(tok, v4, ops)
+        k34 = [r for r in rows4 if r['what'] == 'mv2_conv3']
+        k34_ms = sum(r['ms'] for r in k34)
+        a4 = sum(r['flops'] for r in k34) / (k34_ms * 1e-3) / 1e12 if k34_ms > 0 else 0.0
+        a4x = sum(r['flops_exec'] for r in k34) / (k34_ms * 1e-3) / 1e12 if k34_ms > 0 else 0.0
+        batch4 = dict(workload='BASELINE configs[2] per-GPU shape: (4,3,17,128,128), forward(return_codes, return_recon), HIP graph',
+                      steps=n4, ms_per_step=round(e4 / n4 * 1e3, 4), frames_per_s=round(4 * T * n4 / e4, 1),
+                      conv3=dict(achieved=round(a4, 2), frac=round(a4 / peak, 4), frac_executed=round(a4x / peak, 4),
+                                 avg_launch_ms=round(k34_ms / max(len(k34), 1), 5), launches=len(k34)),
+                      all_kernels_ms_per_step=round(sum(r['ms'] for r in rows4), 4))
+        assert torch.isfinite(r4).all()
+        del v4, c4, r4
+        log(f'batch-4 leg: {batch4["ms_per_step"]} ms/step, conv3 frac {batch4["conv3"]["frac"]}')
 
     # ---- the bit-exact mode on the same workload (driver-visible): fp32 storage + fp32 MFMA
     exact = None
@@ -285,6 +332,7 @@ def main():
     # ---- CPU baseline: the oracle restatement on this box's host cores, bounded sample of the same workload
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1 and not tokenize_only:
+        from oracle import ref_loader
         from oracle.restate import OracleTokenizer
         try:
             navail = len(os.sched_getaffinity(0))
@@ -333,6 +381,33 @@ def main():
                             sample=f'1 clip (1,3,{T},128,128) fp32, {len(timed)} timed run(s) after warm-up, median {med:.2f} s/clip '
                                    f'(bounded to ~{budget:.0f} s of CPU time)',
                             ids_mismatch_vs_gpu=round(mism, 5), recon_mean_abs_diff_vs_gpu=round(derr, 6))
+        # The reference's OWN code (magvit2_pytorch.py:1656-1720 forward) when the build-time copy oracle/_ref is on this box: it becomes
+        # the reported baseline (kind "reference"); the port's figure stays beside it.  Same clip, same thread count, same bound.
+        if ref_loader.reference_available():
+            try:
+                ref = ref_loader.make_reference_tokenizer(**kw)
+                ref.load_state_dict(sd, strict=False)
+                with torch.no_grad():
+                    t1 = time.perf_counter()
+                    rc, rr = ref(vc, return_codes=True, return_recon=True)            # warm-up
+                    log(f'cpu baseline (reference itself, {ref_loader.reference_origin()}): warm-up {time.perf_counter() - t1:.2f} s')
+                    tr = []
+                    while len(tr) < 3 and (not tr or sum(tr) + tr[-1] < budget):
+                        t1 = time.perf_counter()
+                        rc, rr = ref(vc, return_codes=True, return_recon=True)
+                        tr.append(time.perf_counter() - t1)
+                medr = sorted(tr)[len(tr) // 2]
+                cpu_baseline.update(
+                    kind='reference', port_value=cpu_baseline['value'], value=round(T / medr, 3),
+                    source=f'{ref_loader.reference_origin()}: VideoTokenizer.forward(return_codes=True, return_recon=True), magvit2_pytorch.py:1656-1720, '
+                           'loaded under the sys.modules shims of oracle/ref_loader.py (LFQ / Taylor attention from oracle/thirdparty.py: those packages are not vendored)',
+                    sample=f'1 clip (1,3,{T},128,128) fp32, {len(tr)} timed run(s) of the reference after warm-up, median {medr:.2f} s/clip; '
+                           f'the port (oracle/restate.py): {len(timed)} run(s), median {med:.2f} s/clip (each bounded to ~{budget:.0f} s of CPU time)',
+                    reference_ids_equal_port=bool(torch.equal(rc, oc)), reference_recon_max_abs_diff_vs_port=round((rr - orc_recon).abs().max().item(), 8),
+                    ids_mismatch_vs_gpu=round((codes[:1].cpu() != rc).float().mean().item(), 5),
+                    recon_mean_abs_diff_vs_gpu=round((recon[:1].cpu() - rr).abs().mean().item(), 6))
+            except Exception as e:                                                  # the port's figure stands
+                cpu_baseline['reference_error'] = str(e)[:300]
         if exact is not None:
             exact['ids_mismatch_vs_cpu_oracle'] = round((c32[:1].cpu() != oc).float().mean().item(), 5)
             exact['recon_max_abs_diff_vs_cpu_oracle'] = round((r32[:1].cpu() - orc_recon).abs().max().item(), 7)
@@ -353,7 +428,10 @@ def main():
         config=dict(workload=f'{what}; ({B},3,{T},128,128) clip(s) per GPU, README layer spec, random-init weights seed 0',
                     global_batch=B * world, frames_per_clip=T, parallelism=f'dp{world} (clip sharding, no data-path collective)',
                     hip_graph=not args.no_graph),
-        roofline=roofline, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+        roofline=roofline, batch4=batch4, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+    if world > 1:
+        out['rccl_ranks'] = rccl_ranks
+        out['per_rank_ms_per_step'] = rank_ms
     print(json.dumps(out), flush=True)
 
 

@@ -219,6 +219,9 @@ struct C3Lds {
     static constexpr int kLds = kFlag + 16;
     static constexpr int kHtab = 2 * HALO_BYTES;                      // HTAB: [NH][256] row offsets behind the halo images (reduce region: dead during taps)
     static_assert(!MV2_C3_HTAB || kHtab + NH * 256 * 4 <= kMain, "halo offset table fits behind the halo images");
+    // next_seg() writes the NEXT segment's table before the current segment's epilogue runs in the wave-private tiles at smem + wave * PRIV:
+    // nothing between next_seg() and the next tap loop may touch [kHtab, kHtab + NH * 1024)
+    static_assert(!MV2_C3_HTAB || 4 * PRIV <= kHtab, "wave-private epilogue tiles stay below the halo offset table");
     static_assert(kLds <= 80 * 1024, "two workgroups per CU");
 };
 

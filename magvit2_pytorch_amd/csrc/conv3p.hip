@@ -72,19 +72,31 @@ __device__ __forceinline__ void pos_of(int pp, int& ph, int& pw) {     // as con
 // Division of 32-bit unsigned numbers by a launch-time constant (Granlund-Montgomery, the round-up form: exact for every n): a
 // workgroup decodes its block id with five of them; as emulated integer divisions (~40 dependent VALU instructions each, a reciprocal
 // among them) they were 4k of the 6k clocks a workgroup spent before its first load (profiles/r04_findings.md).
-struct FastDiv { uint32_t m, sh1, sh2, d; };
+struct FastDiv { uint32_t m, sh1, sh2; };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
     const uint32_t t = __umulhi(f.m, n);
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 inline FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f; f.d = d;
+    FastDiv f;
     uint32_t l = 0; while ((1ull << l) < d) ++l;
     f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
     f.sh1 = l < 1 ? l : 1; f.sh2 = l > 0 ? l - 1 : 0;
     return f;
 }
-struct P3Params { ConvParams c; FastDiv per_co, S, tiles_sp, T, tiles_w; };
+// Kernel arguments, ordered by first use (the block decode reads the first 24 dwords): ConvParams (conv_common.h) is 400 bytes of which
+// this kernel needs a third, and its scalar loads came in five dependent rounds.
+struct P3Params {
+    FastDiv per_co, S, tiles_sp, T, tiles_w;
+    uint32_t grid;                        // = gridDim.x (the hidden kernel argument sits in another cache line)
+    int32_t B, Ti, Hi, Wi, kt, nchunk, splitk, tiles_w_n, tiles_h_n;
+    int32_t Ci, co, co_pad, out_c, act, act2;
+    uint32_t in_bytes, w_bytes, ws_bytes;
+    float se_bk;
+    const void* in; const void* wp; const float* bias; void* out;
+    float* ws; uint32_t* counters;
+    const void* wp2; const float* bias2; const float* se_wk; float* se_part;
+};
 
 template <int N_> struct WaitVmP;
 #define MV2_WAITVMP(n) template <> struct WaitVmP<n> { static __device__ __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } };
@@ -113,52 +125,53 @@ __device__ unsigned long long* g_conv3p_prof = nullptr;
 #endif
 
 template <bool FUSED>
-__global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
-    const ConvParams& p = pp.c;
+__global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
+    const P3Params& pp = p;
     typedef BF16 E;
     typedef PLds<FUSED> L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const mv2_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cs = wave & 1, kh = wave >> 1;
-    const int T = d.Ti, H = d.Hi, W_ = d.Wi, kt = d.kt, pt = d.kt - 1;
+    const int T = p.Ti, H = p.Hi, W_ = p.Wi, kt = p.kt, pt = p.kt - 1;
     C3P_PROF_DECL
+    asm volatile("" :: "s"(p.in), "s"(p.wp), "s"(p.out), "s"(p.in_bytes));      // every cache line of the kernel arguments is requested in the first round of scalar loads
 
     // ---- block -> (channel tile, batch, frame, spatial tile, K part).  XCD-aware: the blocks of one XCD walk one contiguous eighth of
     // the list = few channel tiles, whose weights stay in that XCD's L2, and neighbouring spatial tiles (shared halo borders).
     uint32_t bid = blockIdx.x;
     {
-        const uint32_t NW = gridDim.x, q = NW >> 3, r = NW & 7, xcd = bid & 7, local = bid >> 3;
+        const uint32_t NW = p.grid, q = NW >> 3, r = NW & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const uint32_t S = (uint32_t)p.splitk, tiles_sp = (uint32_t)(p.tiles_h * p.tiles_w);
-    const uint32_t per_co = (uint32_t)d.B * (uint32_t)T * tiles_sp * S;
+    const uint32_t S = (uint32_t)p.splitk, tiles_sp = (uint32_t)(p.tiles_h_n * p.tiles_w_n);
+    const uint32_t per_co = (uint32_t)p.B * (uint32_t)T * tiles_sp * S;
     const int co_tile = (int)fdiv(bid, pp.per_co);
     uint32_t r_ = bid - (uint32_t)co_tile * per_co, q_;
     q_ = fdiv(r_, pp.S); const uint32_t part = r_ - q_ * S; r_ = q_;
     q_ = fdiv(r_, pp.tiles_sp); const uint32_t sp = r_ - q_ * tiles_sp; r_ = q_;
     const int b = (int)fdiv(r_, pp.T);
     const int t = T - 1 - (int)(r_ - (uint32_t)b * (uint32_t)T);         // descending cost: frames 0 .. kt-2 (fewer valid time taps) are dispatched last
-    const int thi = (int)fdiv(sp, pp.tiles_w), twi = (int)(sp - (uint32_t)thi * (uint32_t)p.tiles_w);
+    const int thi = (int)fdiv(sp, pp.tiles_w), twi = (int)(sp - (uint32_t)thi * (uint32_t)p.tiles_w_n);
     const int v = min(t, pt) + 1;                                       // valid time taps of this output frame (causal front)
     const uint32_t ng = (uint32_t)(p.nchunk * v);                       // groups of nine taps in the tile: (chunk, time tap), chunk-major
     const uint32_t nparts = min(S, ng);
     if (part >= nparts) return;
     // nparts == S: the group list in S nearly equal ranges; nparts == ng < S: one group per part
     const int gb = nparts == S ? (int)fdiv(part * ng, pp.S) : (int)part, ge = nparts == S ? (int)fdiv((part + 1) * ng, pp.S) : (int)part + 1;
-    const uint32_t tile_lin = (((uint32_t)co_tile * (uint32_t)d.B + (uint32_t)b) * (uint32_t)T + (uint32_t)t) * tiles_sp + sp;
+    const uint32_t tile_lin = (((uint32_t)co_tile * (uint32_t)p.B + (uint32_t)b) * (uint32_t)T + (uint32_t)t) * tiles_sp + sp;
     const int h0 = thi * TH, w0 = twi * TW;
     const int n0 = co_tile * BCO;
+    if constexpr (!FUSED) { asm volatile("" :: "s"(gb), "s"(ge), "s"(h0), "s"(w0), "s"(tile_lin)); C3P_SUBP(0) }      // experiments: clocks until the block is decoded
 
-    const uint32_t row_bytes = (uint32_t)d.Ci * 2u;
-    const uint32_t frame_bytes = (uint32_t)((int64_t)H * W_ * d.Ci * 2);
-    const uint32_t w_step = (uint32_t)d.co_pad * 128u;
+    const uint32_t row_bytes = (uint32_t)p.Ci * 2u;
+    const uint32_t frame_bytes = (uint32_t)((int64_t)H * W_ * p.Ci * 2);
+    const uint32_t w_step = (uint32_t)p.co_pad * 128u;
     const uint32_t tapstride = (uint32_t)p.nchunk * w_step;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : (const float*)p.wp), 0,
-                                                                          p.bias ? (uint32_t)d.co_pad * 4u : 0u, 0x00020000);
+                                                                          p.bias ? (uint32_t)p.co_pad * 4u : 0u, 0x00020000);
 
     uint32_t tab[PPW], pb[WPOS];          // halo source table / position-fragment bases: filled in the prologue, behind the first weight loads
     // weights: fragment (step, 32-channel group cg, k-slice ks) of the fragment-major image at step * w_step + (cg * 4 + ks) * 1024
@@ -201,21 +214,28 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
 #pragma unroll
     for (int f = 0; f < RING; ++f) issue_w(cur_wb + (uint32_t)(f >> 1) * tapstride + (uint32_t)(f & 1) * 1024u, wring[f]);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FUSED) { C3P_SUBP(1) }                                                                                 // ... until the weight ring is requested
     // ---- halo source table: DMA piece pi fills image bytes [pi * 1024, pi * 1024 + 1024) = slots pi * 64 + lane (16 B each);
     // slot -> (pixel, part) = (slot / 9, slot % 9); part 8 is the 16-byte padding of the 144-byte pitch.  The entry is the byte offset
     // inside the (frame, chunk) the group reads (the uniform part travels in soffset, which the range check does not see); pixels in
     // the spatial zero padding, the pad part and slots past the image read out of range: zeros, no memory access.
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        int pi = wave + 4 * i;
+    // Each entry's DMA piece is issued as soon as the entry exists: the first pieces are on their way while the later entries and the
+    // fragment bases are computed.
+    const uint32_t so0 = gbase_of(ch0, it0);
+    auto tab_entry = [&](auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        int pi = wave + 4 * I;
         if (pi >= NPIECE) pi -= 2;
         const int slot = pi * 64 + lane;
         const int px = slot / 9, prt = slot - px * 9;
         const int hy = px / HWD, hx = px - hy * HWD;
         const int hin = h0 - 1 + hy, win = w0 - 1 + hx;
         const bool ok = px < HR && prt < 8 && (unsigned)hin < (unsigned)H && (unsigned)win < (unsigned)W_;
-        tab[i] = ok ? (uint32_t)(hin * W_ + win) * row_bytes + (uint32_t)prt * 16u : p.in_bytes;
-    }
+        tab[I] = ok ? (uint32_t)(hin * W_ + win) * row_bytes + (uint32_t)prt * 16u : p.in_bytes;
+        dma_piece(rs_in, so0, 0, i_c);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    tab_entry(IC<0>{}); tab_entry(IC<1>{}); tab_entry(IC<2>{}); tab_entry(IC<3>{}); tab_entry(IC<4>{}); tab_entry(IC<5>{}); tab_entry(IC<6>{});
     // ---- position fragments: MFMA B operand of position tile bb = 16 bytes per lane at (pixel of position 32 bb + l31, k-chunk
     // 2 (2 kh + s) + hi); the nine taps and the two k-steps s of this wave's K half are immediate offsets.
 #pragma unroll
@@ -223,11 +243,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
         int ph, pw; pos_of<TW>(bb * 32 + l31, ph, pw);
         pb[bb] = (uint32_t)(ph * HWD + pw) * ROWP + (uint32_t)(kh * 64 + hi * 16);
     }
-    {
-        const uint32_t so = gbase_of(ch0, it0);
-        dma_piece(rs_in, so, 0, IC<0>{}); dma_piece(rs_in, so, 0, IC<1>{}); dma_piece(rs_in, so, 0, IC<2>{}); dma_piece(rs_in, so, 0, IC<3>{});
-        dma_piece(rs_in, so, 0, IC<4>{}); dma_piece(rs_in, so, 0, IC<5>{}); dma_piece(rs_in, so, 0, IC<6>{});
-    }
+    if constexpr (!FUSED) { asm volatile("" :: "v"(pb[0]), "v"(pb[3])); C3P_SUBP(2) }       // ... until the tables are computed and the first image is requested
     C3P_SUBP(5)
     f32x16 acc[WPOS];
 #pragma unroll
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
 
     // ---- epilogue.  own[j][4 g + q] = channel n0 + 32 cs + 8 g + 4 hi + q of position 32 (2 kh + j) + l31 of the tile.
     const int64_t frame_row0 = ((int64_t)b * T + t) * H;
-    const bool elu1 = d.act == MV2_ACT_ELU;
+    const bool elu1 = p.act == MV2_ACT_ELU;
     if constexpr (!FUSED) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -409,9 +425,9 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
                 const int n = n0 + cs * 32 + gp * 16 + hi * 8;
-                if (pos_ok && n < d.co) {
+                if (pos_ok && n < p.co) {
                     const i32x4 vv = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-                    *(i32x4*)((char*)p.out + (m * d.out_c + n) * 2) = vv;
+                    *(i32x4*)((char*)p.out + (m * p.out_c + n) * 2) = vv;
                 }
             }
         }
@@ -483,9 +499,9 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
             for (int i = 0; i < 4; ++i) {
                 const int row = rr + i * 8;
                 int ph, pw; pos_of<TW>(wave * 32 + row, ph, pw);
-                if ((h0 + ph) < H && (w0 + pw) < W_ && (n0 + ch * 8) < d.co) {
+                if ((h0 + ph) < H && (w0 + pw) < W_ && (n0 + ch * 8) < p.co) {
                     const int64_t m = (frame_row0 + (h0 + ph)) * W_ + (w0 + pw);
-                    *(i32x4*)((char*)p.out + (m * d.out_c + n0 + ch * 8) * 2) = *(const i32x4*)(priv + row * PITCH + ch * 16);
+                    *(i32x4*)((char*)p.out + (m * p.out_c + n0 + ch * 8) * 2) = *(const i32x4*)(priv + row * PITCH + ch * 16);
                 }
             }
         }
@@ -524,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params pp) {
             }
             const int srow = thi * 4 + wave;               // strip row inside the frame (2 image rows each)
             if (srow * 2 < H) {                            // strips below the frame do not exist in the record list
-                float* dst = p.se_part + ((((int64_t)b * T + t) * ((H + 1) / 2) + srow) * p.tiles_w + twi) * (BCO + 2);
+                float* dst = p.se_part + ((((int64_t)b * T + t) * ((H + 1) / 2) + srow) * p.tiles_w_n + twi) * (BCO + 2);
                 dst[2 + lane] = a0 + a1;
                 if (lane == 0) { dst[0] = mx; dst[1] = sw; }
             }
@@ -618,19 +634,16 @@ int conv3p_launch(const mv2_conv_desc* d, const void* in, size_t in_bytes, const
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     if (P.slab_bytes > 0 && (!workspace || workspace_bytes < P.slab_bytes)) return MV2_EWORKSPACE;
     if (P.splitk > 1 && (!counters || counter_bytes < (size_t)P.n_tiles * sizeof(uint32_t))) return MV2_EWORKSPACE;
-    ConvParams p{};
-    p.d = *d; p.in = in; p.wp = wp3; p.bias = bias; p.out = out; p.ws = (float*)workspace;
-    p.wp2 = wp2; p.bias2 = bias2; p.act2 = act2;
-    p.se_wk = se_wk; p.se_bk = se_bk; p.se_part = se_part;
-    p.in_bytes = (uint32_t)in_bytes; p.w_bytes = (uint32_t)w_bytes;
-    p.M = P.M; p.n_co_tiles = P.n_co_tiles; p.n_pos_tiles = (int)(P.n_tiles / P.n_co_tiles);
-    p.splitk = P.splitk; p.tiles_h = P.tiles_h; p.tiles_w = P.tiles_w; p.nchunk = P.nchunk;
-    p.counters = counters; p.ws_bytes = (uint32_t)P.slab_bytes;
-    P3Params pp;
-    pp.c = p;
     const uint32_t tiles_sp = (uint32_t)(P.tiles_h * P.tiles_w);
+    P3Params pp{};
     pp.per_co = make_fastdiv((uint32_t)d->B * (uint32_t)d->Ti * tiles_sp * (uint32_t)P.splitk);
     pp.S = make_fastdiv((uint32_t)P.splitk); pp.tiles_sp = make_fastdiv(tiles_sp); pp.T = make_fastdiv((uint32_t)d->Ti); pp.tiles_w = make_fastdiv((uint32_t)P.tiles_w);
+    pp.grid = (uint32_t)grid;
+    pp.B = d->B; pp.Ti = d->Ti; pp.Hi = d->Hi; pp.Wi = d->Wi; pp.kt = d->kt; pp.nchunk = P.nchunk; pp.splitk = P.splitk; pp.tiles_w_n = P.tiles_w; pp.tiles_h_n = P.tiles_h;
+    pp.Ci = d->Ci; pp.co = d->co; pp.co_pad = d->co_pad; pp.out_c = d->out_c; pp.act = d->act; pp.act2 = act2;
+    pp.in_bytes = (uint32_t)in_bytes; pp.w_bytes = (uint32_t)w_bytes; pp.ws_bytes = (uint32_t)P.slab_bytes; pp.se_bk = se_bk;
+    pp.in = in; pp.wp = wp3; pp.bias = bias; pp.out = out; pp.ws = (float*)workspace; pp.counters = counters;
+    pp.wp2 = wp2; pp.bias2 = bias2; pp.se_wk = se_wk; pp.se_part = se_part;
     return wp2 ? launch3p<true>(pp, (unsigned)grid, st) : launch3p<false>(pp, (unsigned)grid, st);
 }
 

@@ -242,6 +242,7 @@ class Plan:
         self.want_prequant = want_prequant
         self.step_names: List[str] = []
         self.step_flops: Dict[int, float] = {}      # id(step) -> algorithmic FLOPs (conv launches)
+        self.step_flops_exec: Dict[int, float] = {}  # id(step) -> FLOPs the launch executes where that differs (mv2_conv3 skips the causal-front taps)
         self._ticket_buf = None
         ch = self.cfg['channels']
         ops = self.ops
@@ -346,7 +347,13 @@ class Plan:
         segs = pc.segs_tensor(Hi, Wi, Ci, self.ops.device)
         if rms_shift is not None:
             assert rowscale is None
-            if self.ops.conv_rms_ok(d) and not os.environ.get('MV2_NO_CONV_RMS'):
+            # mv2_conv_rms sums the squares of what the K program GATHERS; that is the real row only when every non-filler segment is
+            # fully real.  pack_taps rounds a tap up to a 16-byte chunk: a token-shifted bf16 layer of width 8 gathers 8 elements per
+            # half-row tap, i.e. 4 elements of a neighbouring row under zero weights - the GEMM is right, the fused 1 / |row| is not
+            # (width 16 and above are exact).  Such layers take the separate mv2_rms_rowscale launch.
+            es = 2 if self.dtype == torch.bfloat16 else 4
+            gather_exact = pc.k_real * es == sum(1 for sgt in pc.seg_taps if not sgt[4]) * pc.seg_bytes
+            if gather_exact and self.ops.conv_rms_ok(d) and not os.environ.get('MV2_NO_CONV_RMS'):
                 if in_bytes is None:
                     in_bytes = x.t.numel() * x.t.element_size()
                 steps.append(self.ops.conv_rms(d, x.t, in_bytes, pc.wp, segs, pc.bias, None if residual is None else residual.t, out_t))
@@ -399,7 +406,12 @@ class Plan:
         label = pre + ('.k3+k1' if fuse_k1 else '.k3')
         steps[-1].label = label
         fl = 2.0 * x.rows * pc.co_real * pc.k_real
-        self.step_flops[id(steps[-1])] = fl + (2.0 * x.rows * pc2.co_real * pc2.k_real if fuse_k1 else 0.0)
+        fl2 = 2.0 * x.rows * pc2.co_real * pc2.k_real if fuse_k1 else 0.0
+        self.step_flops[id(steps[-1])] = fl + fl2
+        # the kernel skips the time taps that fall into the causal zero padding (frame t has min(t, kt - 1) + 1 valid taps): the
+        # reference multiplies those zeros, so they count as algorithmic FLOPs but not as matrix-pipe work
+        valid_taps = sum(min(t, pc.kt - 1) + 1 for t in range(x.T))
+        self.step_flops_exec[id(steps[-1])] = fl * valid_taps / float(x.T * pc.kt) + fl2
         self.step_names.append(label)
         if ws is not None:
             self.arena.put(ws)

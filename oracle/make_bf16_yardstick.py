@@ -6,7 +6,7 @@ The "stated fp tolerance" of the bf16 GPU path is the reference's OWN bf16 drift
 sample of a chaotic quantity (a 1-ulp change upstream moves which tokens flip), so the yardstick is taken over several data
 seeds and the GPU test compares MEANS over the same seeds (tests/test_parity_gpu.py::test_bf16_drift_within_reference_yardstick).
 
-    python oracle/make_bf16_yardstick.py            # writes tests/golden/bf16_yardstick.json
+    python oracle/make_bf16_yardstick.py [case ...]  # (re)computes the named cases (default: all) and merges them into tests/golden/bf16_yardstick.json
 
 Per case and data seed: ids mismatch (fraction of tokens), recon mean|d| and max|d| of autocast-bf16 vs fp32, both from the
 reference executed in place (oracle/ref_loader.py).
@@ -31,13 +31,23 @@ CASES = {
     'mid_lfq': (dict(image_size=64, init_dim=16, max_dim=128, codebook_size=1024, layers=README_LAYERS), (1, 3, 9, 64, 64), 5, [6, 101, 102, 103, 104, 105]),
     'cfg2_video128x17': (dict(image_size=128, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (1, 3, 17, 128, 128), 0,
                          [1, 101, 102, 103, 104, 105]),
+    # the two largest fixtures (BASELINE configs[3] and [4]; shapes, weight and data seed of tests/golden/cfg4_* / cfg5_*): ONE draw each
+    # (CPU minutes per clip) - it anchors the single-clip caps of tests/test_parity_gpu.py to the reference instead of to measured HIP values
+    'cfg4_video256x33': (dict(image_size=256, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS), (2, 3, 33, 256, 256), 0, [1]),
+    'cfg5_fsq128x65': (dict(image_size=128, init_dim=64, max_dim=512, use_fsq=True, fsq_levels=[8, 5, 5, 5], layers=README_LAYERS), (2, 3, 65, 128, 128), 0, [1]),
 }
 
 
 def main():
     torch.set_num_threads(os.cpu_count())
     res = dict(torch_version=torch.__version__, note='reference VideoTokenizer, CPU: autocast(bfloat16) vs fp32; see oracle/make_bf16_yardstick.py', cases={})
+    if os.path.exists(OUT):
+        with open(OUT) as f:
+            res['cases'] = json.load(f).get('cases', {})
+    todo = sys.argv[1:] or list(CASES)
     for name, (kw, shape, wseed, dseeds) in CASES.items():
+        if name not in todo:
+            continue
         cfg = make_cfg(**kw)
         sd = init_state_dict(cfg, seed=wseed, randomize_se=True)
         ref = make_reference_tokenizer(**kw)

@@ -1,11 +1,16 @@
 """
 TEST INFRASTRUCTURE — not product code.
 
-Loads the reference's own ``magvit2_pytorch.py`` + ``attend.py`` (read in place from
-/root/reference, never copied) so the *reference itself* can be executed on CPU in the
-authoring container.  It is used to (a) pin ``oracle/restate.py`` and (b) generate the
-golden fixtures under tests/golden/ (``oracle/make_golden.py``).  /root/reference does
-not exist on the GPU box: nothing that runs there may call ``load_reference``.
+Loads the reference's own ``magvit2_pytorch.py`` + ``attend.py`` so the *reference itself* can
+be executed on CPU.  It is used to (a) pin ``oracle/restate.py``, (b) generate the golden
+fixtures under tests/golden/ (``oracle/make_golden.py``) and (c) as the checker / CPU baseline
+on the GPU box (``__graft_entry__.smoke()``, ``bench.py``'s ``cpu_baseline`` leg).
+
+Where it reads from: ``/root/reference`` in the authoring container (read in place).  That path
+does not exist on the GPU box, so ``__graft_entry__.build()`` places a build-time copy of the
+three files it needs under ``oracle/_ref/`` (git-ignored: never part of the repository's
+history; it travels with the gpurun snapshot exactly like the built ``.so``), and this loader
+falls back to that copy.  ``MV2_REFERENCE_ROOT`` overrides both.
 
 The reference is not importable as a package here: its
 ``__init__`` pulls trainer -> data -> cv2 / ema_pytorch / ..., and the model file imports
@@ -24,12 +29,43 @@ import types
 import typing
 import warnings
 
-REFERENCE_ROOT = os.environ.get('MV2_REFERENCE_ROOT', '/root/reference')
+REF_COPY_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
+REF_FILES = ('magvit2_pytorch.py', 'attend.py', 'version.py')
+
+
+def _resolve_root():
+    cands = [os.environ.get('MV2_REFERENCE_ROOT'), '/root/reference', REF_COPY_ROOT]
+    for c in cands:
+        if c and os.path.isfile(os.path.join(c, 'magvit2_pytorch', 'magvit2_pytorch.py')):
+            return c
+    return '/root/reference'
+
+
+REFERENCE_ROOT = _resolve_root()
 _PKG_DIR = os.path.join(REFERENCE_ROOT, 'magvit2_pytorch')
 
 
 def reference_available() -> bool:
     return os.path.isfile(os.path.join(_PKG_DIR, 'magvit2_pytorch.py'))
+
+
+def reference_origin() -> str:
+    """'/root/reference' (authoring container), 'oracle/_ref' (build-time copy) or the override; for log lines."""
+    return 'oracle/_ref (build-time copy of /root/reference/magvit2_pytorch/{magvit2_pytorch,attend,version}.py)' if REFERENCE_ROOT == REF_COPY_ROOT else REFERENCE_ROOT
+
+
+def place_reference_copy(src_root='/root/reference') -> bool:
+    """Build step (``__graft_entry__.build()``): copy the three reference files the loader executes into the git-ignored
+    ``oracle/_ref/magvit2_pytorch/`` so that the GPU box can run the reference itself as the checker and the CPU baseline."""
+    import shutil
+    src = os.path.join(src_root, 'magvit2_pytorch')
+    if not all(os.path.isfile(os.path.join(src, f)) for f in REF_FILES):
+        return False
+    dst = os.path.join(REF_COPY_ROOT, 'magvit2_pytorch')
+    os.makedirs(dst, exist_ok=True)
+    for f in REF_FILES:
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    return True
 
 
 def _stub(name, **attrs):
@@ -84,7 +120,7 @@ def load_reference():
     if _loaded is not None:
         return _loaded
     if not reference_available():
-        raise FileNotFoundError(f'{_PKG_DIR} not present (expected only in the authoring container)')
+        raise FileNotFoundError(f'{_PKG_DIR} not present (neither /root/reference nor the build-time copy oracle/_ref)')
     install_shims()
 
     pkg = types.ModuleType('magvit2_pytorch')

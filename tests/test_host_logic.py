@@ -222,6 +222,34 @@ def test_plan_bf16_storage_within_tolerance():
     assert (g.sample(recon) - g.recon_sample).abs().mean().item() < 1.5e-2
 
 
+def test_token_shifted_width_8_bf16_takes_the_unfused_rms(monkeypatch):
+    """at bf16 width 8 a token-shifted layer's K program gathers 8 elements per half-row tap (taps are rounded up to 16-byte
+    chunks), 4 of them a neighbouring row's under zero weights.  mv2_conv_rms would sum their squares into 1 / |row|; the lowering must
+    take the separate row-scale launch there.  Checked against the RESTATEMENT of the reference (the emulation repeats the kernel's sum,
+    so emulation-vs-HIP tests cannot see this): the bf16 drift of the encoder output must be that of the unfused path, and the lowering
+    must not contain a fused launch for those layers."""
+    kw = dict(image_size=16, init_dim=8, max_dim=16, codebook_size=16, layers=('residual', 'attend_time', 'residual'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    v = torch.randn(2, 3, 5, 16, 16, generator=torch.Generator().manual_seed(4))
+    orc = OracleTokenizer(sd, **cfg)
+    ref_codes, ref_recon = orc(v, return_codes=True, return_recon=True)
+    tok = emulated_tokenizer(kw, sd, torch.bfloat16)
+    codes, recon = tok(v, return_codes=True, return_recon=True)
+    plan, _ = tok._plan(2, 5)
+    names = plan.step_names
+    steps = plan.enc_steps + plan.dec_steps
+    fused = [getattr(st, 'label', '') for st in steps if getattr(st, 'what', '') == 'mv2_conv_rms']
+    assert not any('qkv' in n or 'ff1' in n for n in fused), fused
+    err = (recon - ref_recon).abs().mean().item()
+    monkeypatch.setenv('MV2_NO_CONV_RMS', '1')
+    tok2 = emulated_tokenizer(kw, sd, torch.bfloat16)
+    _, recon2 = tok2(v, return_codes=True, return_recon=True)
+    err2 = (recon2 - ref_recon).abs().mean().item()
+    assert err <= err2 * 1.02 + 1e-6, (err, err2)
+    assert names
+
+
 def test_encode_decode_api_and_multi_codebook():
     kw = dict(image_size=32, init_dim=8, max_dim=32, codebook_size=64, num_codebooks=2,
               layers=('residual', 'compress_space', ('consecutive_residual', 2), 'attend_space', 'compress_time', 'attend_time'))
@@ -554,6 +582,24 @@ def test_c_consumer_builds_and_runs(tmp_path):
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and 'abi smoke ok' in run.stdout, (run.returncode, run.stdout, run.stderr)
+
+
+def test_c_launch_consumer_host_half(tmp_path):
+    """tests/abi/abi_launch.c (the plain-C consumer that launches mv2_conv and mv2_lfq under -m gpu): its host half - test vectors, the C
+    arithmetic that produces the expected buffers and their fixture checksums, the packing and sizing calls - builds with gcc as C99 and runs
+    without a GPU (-DMV2_ABI_LAUNCH_HOST_ONLY)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    lib_dir = os.path.join(ROOT, 'magvit2_pytorch_amd')
+    exe = str(tmp_path / 'abi_launch_host')
+    cc = subprocess.run([gcc, '-std=c99', '-Wall', '-DMV2_ABI_LAUNCH_HOST_ONLY', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'abi', 'abi_launch.c'),
+                         '-L', lib_dir, '-l:libmv2_hip.so', '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and 'host half) ok' in run.stdout, (run.returncode, run.stdout, run.stderr)
 
 
 # ------------------------------------------------------------------------------- facade (CPU emulation of the kernels) vs the reference's own outputs

@@ -53,15 +53,30 @@ def _single_clip_caps(case):
     return 1.25 * max(r['ids_mismatch'] for r in rows), 1.25 * max(r['recon_mean_abs'] for r in rows)
 
 
-# name: (max ids mismatch, max recon mean|d|) for ONE clip; cfg3 is the cfg2 model at batch 4.  cfg4 / cfg5 have no yardstick run
-# (CPU minutes per clip): their caps are the measured HIP values x 1.5 (r02: 1.73 % / 6.81e-3 and 0.23 % / 1.30e-3).
+# name: (max ids mismatch, max recon mean|d|) for ONE clip; cfg3 is the cfg2 model at batch 4.  cfg4 / cfg5: one yardstick draw each, on
+# the fixture's own clips (the reference under autocast(bfloat16) drifts 2.29 % / 7.82e-3 and 0.41 % / 1.71e-3 there; the HIP bf16 mode
+# measured 1.73 % / 6.81e-3 and 0.23 % / 1.30e-3): every gate is anchored to the reference, none to a measured HIP value.
 BF16_GATES = {
     'mid_lfq': _single_clip_caps('mid_lfq'),
     'cfg2_video128x17': _single_clip_caps('cfg2_video128x17'),
     'cfg3_batch4x128x17': _single_clip_caps('cfg2_video128x17'),
-    'cfg4_video256x33': (0.026, 1.02e-2),
-    'cfg5_fsq128x65': (0.005, 1.95e-3),
+    'cfg4_video256x33': _single_clip_caps('cfg4_video256x33'),
+    'cfg5_fsq128x65': _single_clip_caps('cfg5_fsq128x65'),
 }
+# Regression gates BESIDE the yardstick caps: the reconstruction error of the bf16 mode on each fixture as recorded on MI355X
+# (recon mean|d| is smooth from run to run, unlike the id count); a kernel change may not move it by more than 25 %.
+HIP_BF16_RECON_RECORDED = {
+    'mid_lfq': None, 'cfg2_video128x17': 4.05e-3, 'cfg3_batch4x128x17': 4.03e-3, 'cfg4_video256x33': 6.81e-3, 'cfg5_fsq128x65': 1.30e-3,
+}
+
+
+def _check_bf16_gates(name, frac, recon_mean):
+    ids_max, mean_max = BF16_GATES[name]
+    assert frac <= ids_max, f'{frac:.3%} ids differ (gate {ids_max:.2%}: 1.25 x the worst bf16-autocast draw of the reference itself)'
+    assert recon_mean <= mean_max, f'recon mean|d| {recon_mean:.2e} (gate {mean_max:.2e}: 1.25 x the worst bf16-autocast draw of the reference itself)'
+    rec = HIP_BF16_RECON_RECORDED.get(name)
+    if rec is not None:
+        assert recon_mean <= 1.25 * rec, f'recon mean|d| {recon_mean:.2e} regressed against the recorded {rec:.2e}'
 
 # Regression gates on the two SMOOTH halves of the bf16 path (no id flip involved, +-2 % from seed to seed): the encoder up to the
 # quantizer's projection (mean |prequant_bf16 - prequant_fp32|) and the decoder teacher-forced with the fp32 ids.  Values measured on
@@ -222,9 +237,7 @@ def test_bf16_mode_within_stated_tolerance(name):
     frac = (codes.cpu() != g.codes).float().mean().item()
     err = (g.sample(recon.cpu()) - g.recon_sample).abs()
     print(f'[{name}] bf16: ids mismatch {frac:.3%}, recon mean|d| {err.mean().item():.2e} max {err.max().item():.2e}')
-    ids_max, mean_max = BF16_GATES[name]
-    assert frac <= ids_max, f'{frac:.3%} ids differ (gate {ids_max:.1%})'
-    assert err.mean().item() <= mean_max, f'recon mean|d| {err.mean().item():.2e} (gate {mean_max:.1e})'
+    _check_bf16_gates(name, frac, err.mean().item())
     dec = tok.decode_from_code_indices(g.codes.cuda())
     derr = (g.sample(dec.cpu()) - g.recon_sample).abs()
     assert derr.mean().item() <= 1.0e-2 and derr.max().item() <= 0.25
@@ -265,10 +278,10 @@ def test_bf16_drift_within_reference_yardstick(case):
         assert m['dec'] <= 1.10 * base_dec, f'decoder half lost precision: {m["dec"]:.3e} against the recorded {base_dec:.3e}'
 
 
-@pytest.mark.parametrize('name', ['cfg4_video256x33', 'cfg5_fsq128x65'])
+@pytest.mark.parametrize('name', ['cfg3_batch4x128x17', 'cfg4_video256x33', 'cfg5_fsq128x65'])
 def test_full_size_configs_vs_reference_golden(name):
-    """BASELINE configs[3] (256x256x33f: 1024-token space attention, 9-frame time attention, 4096-token linear
-    attention) and configs[4] (FSQ [8,5,5,5], 65 frames) against ids / reconstructions of the reference itself.
+    """BASELINE configs[2] (its per-GPU shape: 4 clips of 17 frames), configs[3] (256x256x33f: 1024-token space attention, 9-frame
+    time attention, 4096-token linear attention) and configs[4] (FSQ [8,5,5,5], 65 frames) against ids / reconstructions of the reference itself.
     The CPU oracle is NOT run at this size: the fixture carries its pre-sign margins.  fp32 mode first (exact
     tolerance), then bf16 mode (stated tolerance)."""
     g = Golden(name)
@@ -294,8 +307,7 @@ def test_full_size_configs_vs_reference_golden(name):
     bfrac = (codes.cpu() != g.codes).float().mean().item()
     err = (g.sample(recon.cpu()) - g.recon_sample).abs()
     print(f'[{name}] fp32 ids mismatch {frac:.4%}; bf16 ids mismatch {bfrac:.3%}, recon mean|d| {err.mean().item():.2e}')
-    ids_max, mean_max = BF16_GATES[name]
-    assert bfrac <= ids_max and err.mean().item() <= mean_max
+    _check_bf16_gates(name, bfrac, err.mean().item())
     assert torch.equal(tok.decode_from_code_indices(codes), recon)      # README round trip at full size
 
 
@@ -633,3 +645,23 @@ def test_lockstep_odd_shapes(case, dtype):
     s = c['kw']['image_size']
     v = torch.randn(c['B'], 3, c['T'], s, s, generator=torch.Generator().manual_seed(60 + case))
     run_lockstep(cfg, sd, v, dtype)
+
+
+def test_c_consumer_launches_kernels(tmp_path):
+    """The C ABI from a compiled C program (no Python, no torch): tests/abi/abi_launch.c allocates with the HIP runtime's C API, packs a weight
+    image with mv2_pack_conv3d, launches mv2_conv and mv2_lfq and compares every element bit-exactly with values computed in C (dyadic test
+    vectors: every partial sum is exact whatever the reduction order) and with the fixture checksums in the file."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'magvit2_pytorch_amd')
+    exe = str(tmp_path / 'abi_launch')
+    cc = subprocess.run([gcc, '-std=c99', '-Wall', '-I', os.path.join(root, 'include'), '-I', '/opt/rocm/include', os.path.join(root, 'tests', 'abi', 'abi_launch.c'),
+                         '-L', lib_dir, '-l:libmv2_hip.so', '-L', '/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and 'abi launch ok' in run.stdout, (run.returncode, run.stdout, run.stderr)

@@ -299,7 +299,7 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
                     printf("        early wg %4d (xcd %d): start +%.0f dur %llu | segs %llu groups %llu taps %llu reduce %llu ticket %llu epi %llu\n", w, w & 7, (double)(hp[w * 16 + 15] - s0),
                            hp[w * 16 + 7], hp[w * 16 + 5], hp[w * 16 + 6], hp[w * 16 + 1], hp[w * 16 + 2], hp[w * 16 + 3], hp[w * 16 + 4]); }
             }
-            if (nw) printf("        epilogue parts per SEGMENT: put_tile %.0f  gemm2 %.0f  put_tile2 %.0f  row stores %.0f  SE %.0f  (to barrier %.0f, barrier %.0f)\n",
+            if (nw) printf("        epilogue parts per SEGMENT (conv3p plain: prologue parts decode / weight ring / tables): put_tile %.0f  gemm2 %.0f  put_tile2 %.0f  row stores %.0f  SE %.0f  (to barrier | conv3p: DMA issue %.0f, barrier | conv3p: landed + barrier %.0f)\n",
                            sub[0] / sum[5], sub[1] / sum[5], sub[2] / sum[5], sub[3] / sum[5], sub[4] / sum[5], sub[5] / sum[5], sub[6] / sum[5]);
         }
         hipFree(dprof);
