@@ -373,6 +373,83 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
         for (int e = 0; e < 9; ++e) dst[(9 + 8 * i + jj) * 9 + e] = a2[jj][e];
 }
 
+// One workgroup per (frame, head) walks ALL tokens of the frame and writes the finished state: no partial states in HBM (the chunked
+// form above wrote 26 partial 73 x 9 states per frame and head - 21 MB per launch at the 32 x 32 level - and a second launch read them
+// back: profiles/r03_findings.md section 4).  thread = (token group tg of 32, feature row i of 8): it keeps the rows [1 + i] and
+// [9 + 8 i .. 9 + 8 i + 7] of the state (81 accumulators, + row 0) over the tokens tg, tg + 32, ..., four tokens in flight per trip; the
+// 32 partial states meet through three xor-shuffles inside a wave (lanes l, l ^ 8, l ^ 16, l ^ 32 hold the same i) and one LDS round
+// across the four waves, summed in a fixed order (bitwise reproducible).
+template <typename E>
+__global__ __launch_bounds__(256) void taylor_kv_frame_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads) {
+    __shared__ float red[4][8][92];
+    const int f = blockIdx.y, h = blockIdx.x;
+    const int tid = threadIdx.x, i = tid & 7, tg = tid >> 3, wave = tid >> 6;
+    const int ld = 2 * heads * 8;
+    constexpr int NC = 8 / E::kVec, U = 4;
+    float a2[8][9], a1[9], a0[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { a1[e] = 0.f; a0[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
+    const float r2 = 0.70710678118654752440f;
+    for (int t0 = tg; t0 < n; t0 += 32 * U) {
+        i32x4 kr[U][NC], vr[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + 32 * u, n - 1);                  // clamped: the tail trip re-reads a valid row and is masked below
+            const int64_t row = ((int64_t)f * n + t) * ld;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                kr[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
+                vr[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float k[8], v[9];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kr[u][c], k + c * E::kVec); Chunk<E>::unpack(vr[u][c], v + c * E::kVec); }
+            const bool live = t0 + 32 * u < n;
+            v[8] = live ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = live ? v[e] : 0.f;
+            float ki = k[0];
+#pragma unroll
+            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float ph = (ki * k[jj]) * r2;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
+            }
+        }
+    }
+    // the eight token groups of a wave: lanes with equal i
+    auto wred = [&](float x) { x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); return x; };
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { a0[e] = wred(a0[e]); a1[e] = wred(a1[e]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a2[jj][e] = wred(a2[jj][e]); }
+    if ((tid & 63) < 8) {
+        float* r = red[wave][i];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { r[e] = a0[e]; r[9 + e] = a1[e];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) r[18 + jj * 9 + e] = a2[jj][e]; }
+    }
+    __syncthreads();
+    float* dst = state + ((int64_t)f * heads + h) * TAY_S;
+    for (int x = tid; x < 8 * 90; x += 256) {
+        const int ii = x / 90, r = x - ii * 90;
+        const float s = ((red[0][ii][r] + red[1][ii][r]) + red[2][ii][r]) + red[3][ii][r];
+        if (r < 9) { if (ii == 0) dst[r] = s; }                                   // row 0: sum of [v, 1] (every i holds a copy)
+        else if (r < 18) dst[(1 + ii) * 9 + (r - 9)] = s;                          // row 1 + i
+        else dst[(9 + 8 * ii + (r - 18) / 9) * 9 + (r - 18) % 9] = s;             // row 9 + 8 i + j
+    }
+}
+
 __global__ __launch_bounds__(256) void taylor_reduce_kernel(const float* __restrict__ part, float* __restrict__ kvsum, int heads,
                                                             int nchunk) {
     const int fh = blockIdx.x;             // frame * heads + head
@@ -427,8 +504,10 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
 #pragma unroll
             for (int d = 0; d < 8; ++d) qv[u][d] *= scale;
         }
+        // The state rows are read in BATCHES of eight (rows 1..8, then the eight rows of every i): the 24 LDS reads of a batch are in flight
+        // together, so a batch pays one LDS latency.  (A compiler barrier per ROW kept the unrolled code from hoisting all 73 rows into
+        // registers, but exposed 73 LDS round trips per trip of a wave that is alone on its SIMD; the barriers now sit between batches.)
         auto row9 = [&](int r, float* s9) {
-            asm volatile("" ::: "memory");                         // keep the fully unrolled loop from hoisting all 73 rows (spills)
             const f32x4 a = *(const f32x4*)(S + r * TAY_LP), b = *(const f32x4*)(S + r * TAY_LP + 4), c = *(const f32x4*)(S + r * TAY_LP + 8);
             s9[0] = a[0]; s9[1] = a[1]; s9[2] = a[2]; s9[3] = a[3]; s9[4] = b[0]; s9[5] = b[1]; s9[6] = b[2]; s9[7] = b[3]; s9[8] = c[0];
         };
@@ -439,13 +518,17 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
 #pragma unroll
                 for (int e = 0; e < 9; ++e) acc[u][e] = s9[e];
         }
+        asm volatile("" ::: "memory");
+        {
+            float s8[8][9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float s9[9]; row9(1 + i, s9);
+            for (int i = 0; i < 8; ++i) row9(1 + i, s8[i]);
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int e = 0; e < 9; ++e) acc[u][e] += qv[u][i] * s9[e];
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) acc[u][e] += qv[u][i] * s8[i][e];
         }
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {                              // a real loop: unrolled, the 256 products q_i q_j were all hoisted (spills)
@@ -457,14 +540,17 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
                 for (int k = 1; k < 8; ++k) qi[u] = (i == k) ? qv[u][k] : qi[u];
                 qi[u] *= r2;
             }
+            asm volatile("" ::: "memory");
+            float s8[8][9];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) row9(9 + 8 * i + jj, s8[jj]);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                float s9[9]; row9(9 + 8 * i + jj, s9);
 #pragma unroll
                 for (int u = 0; u < NT; ++u) {
                     const float ph = qi[u] * qv[u][jj];
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) acc[u][e] += ph * s9[e];
+                    for (int e = 0; e < 9; ++e) acc[u][e] += ph * s8[jj][e];
                 }
             }
         }
@@ -486,9 +572,16 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
 extern "C" int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames, int n, int heads, int nchunk, void* stream) {
     if (!kv || !part || frames <= 0 || n <= 0 || heads <= 0 || heads > 32 || nchunk <= 0 || nchunk > n) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (nchunk == 1) {      // one workgroup per (frame, head) over all tokens: `part` receives the finished states [frames][heads][657]
+        dim3 gridf((unsigned)heads, (unsigned)frames);
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_frame_kernel<BF16>), gridf, dim3(256), 0, st, kv, part, n, heads);
+        else hipLaunchKernelGGL((taylor_kv_frame_kernel<F32>), gridf, dim3(256), 0, st, kv, part, n, heads);
+        MV2_LAUNCH_CHECK();
+        return MV2_OK;
+    }
     dim3 grid((unsigned)nchunk, (unsigned)frames);
     const unsigned threads = (unsigned)(heads * 8);
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_kernel<BF16>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);
     else hipLaunchKernelGGL((taylor_kv_kernel<F32>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);
     MV2_LAUNCH_CHECK();
@@ -502,11 +595,15 @@ extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, voi
     const size_t lds = (size_t)heads * TAY_F * TAY_LP * sizeof(float);
     if (lds > 64 * 1024) return MV2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0, st, part, kvsum_ws, heads, nchunk);
-    MV2_LAUNCH_CHECK();
+    const float* kvsum = kvsum_ws;
+    if (nchunk == 1) kvsum = part;      // mv2_taylor_kv with nchunk == 1 wrote the finished states: nothing to reduce
+    else {
+        hipLaunchKernelGGL(taylor_reduce_kernel, dim3((unsigned)(frames * heads)), dim3(256), 0, st, part, kvsum_ws, heads, nchunk);
+        MV2_LAUNCH_CHECK();
+    }
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)frames);
-    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_kernel<BF16>), grid, dim3(256), lds, st, q, kvsum_ws, out, n, heads);
-    else hipLaunchKernelGGL((taylor_apply_kernel<F32>), grid, dim3(256), lds, st, q, kvsum_ws, out, n, heads);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_kernel<BF16>), grid, dim3(256), lds, st, q, kvsum, out, n, heads);
+    else hipLaunchKernelGGL((taylor_apply_kernel<F32>), grid, dim3(256), lds, st, q, kvsum, out, n, heads);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }

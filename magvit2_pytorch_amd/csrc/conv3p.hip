@@ -46,6 +46,9 @@ constexpr int RING = 6;                                               // weight 
 #ifndef MV2_C3P_ILV
 #define MV2_C3P_ILV 1
 #endif
+#ifndef MV2_C3P_PRIO
+#define MV2_C3P_PRIO 0
+#endif
 constexpr int SLAB = BCO * BPOS * 4;
 constexpr int XCH = 4 * 8192;                                         // exchange region: [wave][2 tiles][4][64 lanes][16 B]
 static_assert(NPIECE == 26 && PPW == 7, "piece bookkeeping below");
@@ -135,6 +138,10 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     const int cs = wave & 1, kh = wave >> 1;
     const int T = p.Ti, H = p.Hi, W_ = p.Wi, kt = p.kt, pt = p.kt - 1;
     C3P_PROF_DECL
+    // PRIO: the fixed phases (prologue, exchange, slab / ticket, epilogue) run at raised issue priority, the tap loop at 0: a workgroup
+    // in a fixed phase issues little, but every instruction of it otherwise queues behind the MFMA / LDS streams of the two workgroups
+    // that share its SIMDs, and the sooner it is through the sooner the matrix pipe has three tap streams again.
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     asm volatile("" :: "s"(p.in), "s"(p.wp), "s"(p.out), "s"(p.in_bytes));      // every cache line of the kernel arguments is requested in the first round of scalar loads
 
     // ---- block -> (channel tile, batch, frame, spatial tile, K part).  XCD-aware: the blocks of one XCD walk one contiguous eighth of
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     read_p(pb, 0, IC<0>{});
     C3P_SUBP(6)
     C3P_PROF(0)
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(0);
 
     for (int gi = gb; gi < ge; ++gi) {
         const int par = (gi - gb) & 1;
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         if (gi + 2 < ge) advance1();
         nxt_wb = wbase_of(c1, i1);
     }
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     WaitVmP<0>::run();                                // every DMA write of this wave (and its trailing weight prefetch) has landed ...
     __syncthreads();                                  // ... everybody's: LDS becomes the exchange region
     // bias of this wave's 16 channels per lane (channel 32 cs + 8 g + 4 hi + j): requested now, lands under the exchange
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
             if (half == 0) ev[row] = e;
             __builtin_amdgcn_wave_barrier();
             float a0 = 0.f, a1 = 0.f;                     // lane = channel
-#pragma unroll 4
+#pragma unroll
             for (int r = 0; r < 32; r += 2) {
                 a0 += ev[r] * bf2f(*(const unsigned short*)(priv + r * PITCH + lane * 2));
                 a1 += ev[r + 1] * bf2f(*(const unsigned short*)(priv + (r + 1) * PITCH + lane * 2));

@@ -325,7 +325,7 @@ class HipOps:
     def taylor_apply(self, dt, q, part, out, kvsum, frames, n, heads, nchunk):
         fn, args = self.lib.mv2_taylor_apply, (dt, _ptr(q), _ptr(part), _ptr(out), _ptr(kvsum), frames, n, heads, nchunk)
         keep = (q, part, out, kvsum)
-        return _mk(fn, args, 'mv2_taylor_apply', keep, [out, kvsum])
+        return _mk(fn, args, 'mv2_taylor_apply', keep, [out, kvsum] if nchunk > 1 else [out])      # nchunk == 1: kvsum is not written
 
     def lfq(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
         fn = self.lib.mv2_lfq

@@ -608,7 +608,9 @@ class Plan:
         q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
         kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
         frames, n = x.B * x.T, x.H * x.W
-        nchunk = max(1, min(n // 32 if n >= 32 else 1, -(-int(os.environ.get('MV2_TAYLOR_BLOCKS', '512')) // frames)))
+        # one workgroup per (frame, head) accumulates the whole frame's state (mv2_taylor_kv with nchunk = 1): no partial states in HBM and no
+        # reduce launch (the chunked form, nchunk > 1, stays in the ABI for frames too long for one workgroup's patience)
+        nchunk = 1
         part = self.arena.get(frames * nchunk * heads * 657, torch.float32)
         kvsum = self.arena.get(frames * heads * 657, torch.float32)
         o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)

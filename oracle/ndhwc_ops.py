@@ -609,12 +609,13 @@ class CpuOps:
     def taylor_apply(self, dt, q, part, out, kvsum, frames, n, heads, nchunk):
         def step(stream):
             S = part[: frames * nchunk * heads * 657].reshape(frames, nchunk, heads, 73, 9).to(self.acc).sum(dim=1)
-            kvsum[: frames * heads * 657].copy_(S.reshape(-1).float())
+            if nchunk > 1:                       # nchunk == 1: `part` already holds the finished states, the library does not touch kvsum
+                kvsum[: frames * heads * 657].copy_(S.reshape(-1).float())
             qq = q[: frames * n * heads * 8].reshape(frames, n, heads, 8).to(self.acc) * 8 ** -0.5
             acc = torch.einsum('fnhd,fhde->fnhe', self._phi(qq), S)
             o = acc[..., :8] * (1.0 / acc[..., 8:].clamp(min=1e-5))
             out[: frames * n * heads * 8].copy_(o.reshape(-1).to(out.dtype))
-        step.outs = [o for o in [out, kvsum] if o is not None]
+        step.outs = [o for o in ([out, kvsum] if nchunk > 1 else [out]) if o is not None]
         step.what = 'taylor_apply'
         return step
 

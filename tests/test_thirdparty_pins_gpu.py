@@ -102,19 +102,22 @@ def test_fsq_all_1000_ids_round_trip_and_level_table():
     assert torch.equal(q.reshape(n, C)[:, :d].cpu().double(), expect)
 
 
-def test_taylor_linear_attention_hand_computed_four_tokens():
+@pytest.mark.parametrize('n,nchunk', [(4, 1), (4, 2), (133, 1), (133, 3)])
+def test_taylor_linear_attention_hand_computed_four_tokens(n, nchunk):
+    """n = 4: the hand-computable case; n = 133: a ragged frame (the whole-frame kernel's 32 token groups x 4 tokens per trip with a masked
+    tail).  nchunk = 1 is the whole-frame state kernel (no partial states, no reduce), nchunk > 1 the chunked form that stays in the ABI."""
     ops = _ops()
-    heads, dh, n, frames = 16, 8, 4, 1
+    heads, dh, frames = 16, 8, 1
     g = torch.Generator().manual_seed(11)
     q = torch.randn(n, heads * dh, generator=g) * 0.7
     kv = torch.randn(n, 2 * heads * dh, generator=g) * 0.7
     dev = ops.device
-    part = torch.empty(frames * 1 * heads * 657, dtype=torch.float32, device=dev)
+    part = torch.empty(frames * nchunk * heads * 657, dtype=torch.float32, device=dev)
     kvsum = torch.empty(frames * heads * 657, dtype=torch.float32, device=dev)
     out = torch.empty(n * heads * dh, dtype=torch.float32, device=dev)
     st = ops.current_stream()
-    ops.taylor_kv(P.MV2_F32, kv.to(dev).reshape(-1), part, frames, n, heads, 1)(st)
-    ops.taylor_apply(P.MV2_F32, q.to(dev).reshape(-1), part, out, kvsum, frames, n, heads, 1)(st)
+    ops.taylor_kv(P.MV2_F32, kv.to(dev).reshape(-1), part, frames, n, heads, nchunk)(st)
+    ops.taylor_apply(P.MV2_F32, q.to(dev).reshape(-1), part, out, kvsum, frames, n, heads, nchunk)(st)
     ops.synchronize()
     got = out.reshape(n, heads, dh).cpu().double().numpy()
 
@@ -130,7 +133,7 @@ def test_taylor_linear_attention_hand_computed_four_tokens():
         for t in range(n):
             f = phi(qn[t, h * dh:(h + 1) * dh] * dh ** -0.5)
             exp[t, h] = f @ KV / max(f @ Ks, 1e-5)
-    assert np.abs(got - exp).max() <= 2e-5, np.abs(got - exp).max()
+    assert np.abs(got - exp).max() <= (2e-5 if n <= 8 else 2e-4), np.abs(got - exp).max()
 
 
 # ------------------------------------------------------------------------------- RCCL: first contact when a multi-GPU box appears
