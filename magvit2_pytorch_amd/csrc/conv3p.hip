@@ -324,6 +324,18 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     C3P_PROF_COUNT(5, 1)
     C3P_PROF_COUNT(6, (unsigned long long)(ge - gb))
 
+    // fused second stage: its operands are requested now (their round trips hide under the exchange): W2 fragments straight from the plain
+    // packed image [row 64][128 B] (lane: row 32 a + l31, chunk 2 ks + hi), bias2 / se_wk for the LDS constants
+    i32x4 w2f[2][4];
+    f32x4 c2v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w2f[a][ks] = *(const i32x4*)((const char*)p.wp2 + (size_t)(a * 32 + l31) * 128 + (size_t)(2 * ks + hi) * 16);
+        if (tid < 16) { if (p.bias2) c2v = *(const f32x4*)(p.bias2 + tid * 4); }
+        else if (tid < 32) { if (p.se_wk) c2v = *(const f32x4*)(p.se_wk + (tid - 16) * 4); }
+    }
     // ---- 2-way exchange between the K halves: wave (cs, kh) keeps position tiles 2 kh, 2 kh + 1 and hands the other two to its partner
     // (cs, 1 - kh).  a + b == b + a bitwise, so both partners form the same sum.
     f32x16 own[2];
@@ -445,14 +457,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         // out[co][pos] = sum_k W2[co][k] * tile[pos][k] for position tile w2 (K = 64 = four k-steps), bias2 + ELU, stores whole rows out of
         // a wave-private LDS tile and writes the SqueezeExcite pooling record of its 2 x 16 strip (conv3.hip's epilogue, unchanged values).
         constexpr int PITCH = ROWP;
-        // W2 fragments straight from the plain packed image [row 64][128 B]: lane (row 32 a + l31, chunk 2 ks + hi)
-        i32x4 w2f[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w2f[a][ks] = *(const i32x4*)((const char*)p.wp2 + (size_t)(a * 32 + l31) * 128 + (size_t)(2 * ks + hi) * 16);
-        if (tid < 16) *(f32x4*)(smem + L::kConst2 + tid * 16) = p.bias2 ? *(const f32x4*)(p.bias2 + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        else if (tid < 32) *(f32x4*)(smem + L::kConst2 + tid * 16) = p.se_wk ? *(const f32x4*)(p.se_wk + (tid - 16) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < 32) *(f32x4*)(smem + L::kConst2 + tid * 16) = c2v;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             char* rowp = smem + L::kY1 + ((2 * kh + j) * 32 + l31) * PITCH;

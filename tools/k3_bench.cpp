@@ -502,6 +502,12 @@ int main(int argc, char** argv) {
             time_pointwise("kv C=256 T=20", 20, 32, 256, 256, MV2_ACT_NONE, false, st2);
             time_pointwise("ff1 B=4 C=512 T=20 (geglu)", 80, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2);
             time_pointwise("ff2 B=4 C=512 T=20", 80, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+            // short-K launches whose 128 x 128 tiles are all epilogue (r04: 16-22k of 30k clocks per block)
+            time_pointwise("up2x2 128->64 64x64 silu (dec.12)", 20, 64, 128, 256, MV2_ACT_SILU, false, st2, false, 2);
+            time_pointwise("up2x2 256->128 32x32 silu (dec.10)", 20, 32, 256, 512, MV2_ACT_SILU, false, st2, false, 2);
+            time_pointwise("up2x2 512->256 16x16 silu (dec.7)", 20, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 2);
+            time_pointwise("kv C=256 T=20 (512 cols)", 20, 32, 256, 512, MV2_ACT_NONE, false, st2);
+            time_pointwise("ff1 C=256 T=20 (geglu)", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2);
         }
         return 0;
     }

@@ -49,7 +49,7 @@ def main(src, tag, dst):
     fs = ws = 0.0
     nf = nw = 0
     for k in per:
-        if 'conv3_kernel' in k:
+        if 'conv3p_kernel' in k or 'conv3_kernel' in k:      # mv2_conv3: the bf16 position-tile kernel (conv3p.hip) / the fp32 K-split kernel (conv3.hip)
             fs += per[k]['FETCH_SIZE'][0]; nf += launches[k].get('pmc_fetch', 0)
             ws += per[k]['WRITE_SIZE'][0]; nw += launches[k].get('pmc_write', 0)
     if nf and nw:
@@ -57,13 +57,13 @@ def main(src, tag, dst):
         import hashlib
         h = hashlib.sha256()
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for fn in ('conv3.hip', 'conv_common.h', 'common.h'):                      # bench.py::kernel_source_hash
+        for fn in ('conv3.hip', 'conv3p.hip', 'conv3p.h', 'conv_common.h', 'common.h'):      # bench.py::kernel_source_hash
             with open(os.path.join(root, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
                 h.update(f.read())
         js = dict(conv3_kernel_hbm_bytes_per_launch=int((2 * fetch_kb + write_kb) * 1024), launches_averaged=nf,
                   kernel_source_sha256=h.hexdigest(),
                   fetch_size_kb_avg=round(fetch_kb, 1), write_size_kb_avg=round(write_kb, 1),
-                  note='rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 3 --no-graph` (B=1, bf16), averaged over all conv3_kernel '
+                  note='rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 3 --no-graph` (B=1, bf16), averaged over all mv2_conv3 '
                        'launches (22 per forward); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a 16 B/lane coalesced '
                        'stream), WRITE_SIZE as reported. Counts L2<->fabric bytes, i.e. MALL hits are included. Algorithmic bytes per launch '
                        '~31 MB (11.2 MB in + 11.2 MB out + 8.5 MB weights on average).')
