@@ -63,20 +63,20 @@ BF16_GATES = {
     'cfg4_video256x33': _single_clip_caps('cfg4_video256x33'),
     'cfg5_fsq128x65': _single_clip_caps('cfg5_fsq128x65'),
 }
-# Regression gates BESIDE the yardstick caps: the reconstruction error of the bf16 mode on each fixture as recorded on MI355X
-# (recon mean|d| is smooth from run to run, unlike the id count); a kernel change may not move it by more than 25 %.
-HIP_BF16_RECON_RECORDED = {
-    'mid_lfq': None, 'cfg2_video128x17': 4.05e-3, 'cfg3_batch4x128x17': 4.03e-3, 'cfg4_video256x33': 6.81e-3, 'cfg5_fsq128x65': 1.30e-3,
-}
+# Regression gates BESIDE the yardstick caps, on a SMOOTH quantity: the decoder alone, teacher-forced with the golden ids (no id
+# flip involved; the full reconstruction error moves with the number of flipped ids, 0.9-1.4 % from one summation order to the next).
+# The gate is the reference's own decoder-only bf16 drift on the same model (yardstick `decoder_only_mean_abs`, mean over its draws) x 1.05;
+# the HIP bf16 mode sits 10-25 % below it (cfg2: 1.87e-3 against 2.10e-3), so a kernel that loses precision trips it.
+def _decoder_only_gate(name):
+    case = {'cfg3_batch4x128x17': 'cfg2_video128x17'}.get(name, name)
+    rows = _yardstick()[case]['rows']
+    return 1.05 * sum(r['decoder_only_mean_abs'] for r in rows) / len(rows)
 
 
 def _check_bf16_gates(name, frac, recon_mean):
     ids_max, mean_max = BF16_GATES[name]
     assert frac <= ids_max, f'{frac:.3%} ids differ (gate {ids_max:.2%}: 1.25 x the worst bf16-autocast draw of the reference itself)'
     assert recon_mean <= mean_max, f'recon mean|d| {recon_mean:.2e} (gate {mean_max:.2e}: 1.25 x the worst bf16-autocast draw of the reference itself)'
-    rec = HIP_BF16_RECON_RECORDED.get(name)
-    if rec is not None:
-        assert recon_mean <= 1.25 * rec, f'recon mean|d| {recon_mean:.2e} regressed against the recorded {rec:.2e}'
 
 # Regression gates on the two SMOOTH halves of the bf16 path (no id flip involved, +-2 % from seed to seed): the encoder up to the
 # quantizer's projection (mean |prequant_bf16 - prequant_fp32|) and the decoder teacher-forced with the fp32 ids.  Values measured on
@@ -240,7 +240,8 @@ def test_bf16_mode_within_stated_tolerance(name):
     _check_bf16_gates(name, frac, err.mean().item())
     dec = tok.decode_from_code_indices(g.codes.cuda())
     derr = (g.sample(dec.cpu()) - g.recon_sample).abs()
-    assert derr.mean().item() <= 1.0e-2 and derr.max().item() <= 0.25
+    print(f'[{name}] bf16 decoder alone (golden ids): mean|d| {derr.mean().item():.3e} (gate {_decoder_only_gate(name):.3e})')
+    assert derr.mean().item() <= _decoder_only_gate(name) and derr.max().item() <= 0.25
 
 
 @pytest.mark.parametrize('case', ['mid_lfq', 'cfg2_video128x17'])
@@ -309,6 +310,9 @@ def test_full_size_configs_vs_reference_golden(name):
     print(f'[{name}] fp32 ids mismatch {frac:.4%}; bf16 ids mismatch {bfrac:.3%}, recon mean|d| {err.mean().item():.2e}')
     _check_bf16_gates(name, bfrac, err.mean().item())
     assert torch.equal(tok.decode_from_code_indices(codes), recon)      # README round trip at full size
+    derr = (g.sample(tok.decode_from_code_indices(g.codes.cuda()).cpu()) - g.recon_sample).abs()      # decoder alone in bf16: the smooth regression gate
+    print(f'[{name}] bf16 decoder alone (golden ids): mean|d| {derr.mean().item():.3e} (gate {_decoder_only_gate(name):.3e})')
+    assert derr.mean().item() <= _decoder_only_gate(name)
 
 
 # ------------------------------------------------------------------------------- size-independent properties

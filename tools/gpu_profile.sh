@@ -9,7 +9,7 @@ cd $R
 (timeout 300 python bench.py --config 2 --steps 100 --no-cpu-baseline --no-exact --breakdown $O/${TAG}_per_launch_events_b4.json 2>&1 | tail -3) > $O/${TAG}_bench_b4.log 2>&1
 (timeout 300 python bench.py --config 4 --steps 100 --no-cpu-baseline 2>&1 | tail -3) > $O/${TAG}_bench_cfg4_fsq.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact --no-graph --no-soak"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact --no-batch4 --no-graph --no-soak"
 (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- $BENCH > $O/${TAG}_rocprof.log 2>&1)
 if [ "$PMC" = "pmc" ]; then
   (timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq -- $BENCH > $O/${TAG}_pmc_sq.log 2>&1)
