@@ -170,9 +170,11 @@ int mv2_conv_out(const mv2_conv_desc* d, const void* in, size_t in_bytes, const 
  *      pooling partials of every 2 x 16 strip of positions of every frame in mv2_se_pool's record format
  *        se_part[(frame * n + j) * (C + 2)] = {max logit, sum exp, exp-weighted channel sums[C]},
  *      n = mv2_conv3_tiles(d, &th, &tw) strips of th x tw = 2 x 16 positions per frame, j = strip_row * ceil(W/16) + strip_col.
- * Work split: one workgroup per CU walks an equal share of the (tile, chunk, time-tap) list; a tile shared by
- *      several workgroups is combined in-kernel (fp32 partials in `workspace`, a ticket per tile in `counters`, summed
- *      in a fixed order: results are bitwise reproducible).  workspace: mv2_conv3_workspace_bytes(d) bytes, contents
+ * Work split: one workgroup per (64-channel x 8x16-position tile, K part): launches with fewer tiles than the chip has workgroup
+ *      slots (the deepest levels at batch 1) cut every tile's (chunk, time-tap) list into parts; the parts of a tile are combined
+ *      in-kernel (fp32 partials in `workspace`, a ticket per tile in `counters`, summed in part order: results are bitwise
+ *      reproducible).  (bf16: conv3p.hip; the exact-fp32 mode walks equal shares of the list per CU, conv3.hip - same contract.)
+ *      workspace: mv2_conv3_workspace_bytes(d) bytes (0 when no tile is split), contents
  *      irrelevant.  counters: mv2_conv3_counter_bytes(d) bytes that MUST BE ZERO when the launch starts; the kernel
  *      leaves them zero, so one zero-initialised buffer can serve every mv2_conv3 launch of a stream.
  * ------------------------------------------------------------------------------------------- */

@@ -42,12 +42,21 @@ constexpr int ROWP = 144;                                             // LDS pit
 constexpr int NPIECE = (HR * ROWP + 1023) / 1024;                     // 1 KB DMA pieces per halo image (26)
 constexpr int IMG = NPIECE * 1024;
 constexpr int PPW = (NPIECE + 3) / 4;                                 // pieces per wave (7; waves 2, 3 repeat pieces 24, 25)
-constexpr int RING = 6;                                               // weight fragments in flight per wave (3 taps)
+#ifndef MV2_C3P_RING
+#define MV2_C3P_RING 6
+#endif
+constexpr int RING = MV2_C3P_RING;                                    // weight fragments in flight per wave (6 = 3 taps; must divide the 18 fragments of a group)
+static_assert(18 % RING == 0, "ring slots must divide the 18 fragments of a group");
 #ifndef MV2_C3P_ILV
 #define MV2_C3P_ILV 1
 #endif
 #ifndef MV2_C3P_PRIO
 #define MV2_C3P_PRIO 0
+#endif
+// ABL (experiments, TIMING ONLY - results are wrong): 1 = the next group's halo is never requested (no DMA issue in the tap loop),
+// 2 = 1 + no group barrier, 3 = 2 + no weight reloads, 4 = 3 + no fragment reads (bare MFMA stream).  What a wave ALONE on its SIMD loses where.
+#ifndef MV2_C3P_ABL
+#define MV2_C3P_ABL 0
 #endif
 constexpr int SLAB = BCO * BPOS * 4;
 constexpr int XCH = 4 * 8192;                                         // exchange region: [wave][2 tiles][4][64 lanes][16 B]
@@ -92,6 +101,7 @@ inline FastDiv make_fastdiv(uint32_t d) {
 struct P3Params {
     FastDiv per_co, S, tiles_sp, T, tiles_w;
     uint32_t grid;                        // = gridDim.x (the hidden kernel argument sits in another cache line)
+    int32_t time_inner;                   // block order inside a (channel tile, clip): 1 = frames inside spatial tiles, 0 = spatial tiles inside frames
     int32_t B, Ti, Hi, Wi, kt, nchunk, splitk, tiles_w_n, tiles_h_n;
     int32_t Ci, co, co_pad, out_c, act, act2;
     uint32_t in_bytes, w_bytes, ws_bytes;
@@ -103,7 +113,7 @@ struct P3Params {
 
 template <int N_> struct WaitVmP;
 #define MV2_WAITVMP(n) template <> struct WaitVmP<n> { static __device__ __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } };
-MV2_WAITVMP(0) MV2_WAITVMP(6)
+MV2_WAITVMP(0) MV2_WAITVMP(6) MV2_WAITVMP(9)
 #undef MV2_WAITVMP
 
 }  // namespace
@@ -156,9 +166,18 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     const int co_tile = (int)fdiv(bid, pp.per_co);
     uint32_t r_ = bid - (uint32_t)co_tile * per_co, q_;
     q_ = fdiv(r_, pp.S); const uint32_t part = r_ - q_ * S; r_ = q_;
-    q_ = fdiv(r_, pp.tiles_sp); const uint32_t sp = r_ - q_ * tiles_sp; r_ = q_;
-    const int b = (int)fdiv(r_, pp.T);
-    const int t = T - 1 - (int)(r_ - (uint32_t)b * (uint32_t)T);         // descending cost: frames 0 .. kt-2 (fewer valid time taps) are dispatched last
+    // time_inner: the blocks of a spatial tile's T frames are neighbours in the list (and on one XCD), so the three output frames that read
+    // an input frame's halo run close together and two of the three reads hit that XCD's L2; otherwise frames are the outer loop
+    // (descending, so that the cheap causal-front frames come last and fill the tail).
+    uint32_t sp; int b, t;
+    if (p.time_inner) {
+        q_ = fdiv(r_, pp.T); t = T - 1 - (int)(r_ - q_ * (uint32_t)T); r_ = q_;
+        b = (int)fdiv(r_, pp.tiles_sp); sp = r_ - (uint32_t)b * tiles_sp;
+    } else {
+        q_ = fdiv(r_, pp.tiles_sp); sp = r_ - q_ * tiles_sp; r_ = q_;
+        b = (int)fdiv(r_, pp.T);
+        t = T - 1 - (int)(r_ - (uint32_t)b * (uint32_t)T);
+    }
     const int thi = (int)fdiv(sp, pp.tiles_w), twi = (int)(sp - (uint32_t)thi * (uint32_t)p.tiles_w_n);
     const int v = min(t, pt) + 1;                                       // valid time taps of this output frame (causal front)
     const uint32_t ng = (uint32_t)(p.nchunk * v);                       // groups of nine taps in the tile: (chunk, time tap), chunk-major
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
                 // everybody's: the barrier), and nobody reads this group's image any more (its last fragments are in registers)
                 WaitVmP<RING>::run();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (MV2_C3P_ABL < 2) __builtin_amdgcn_s_barrier();
                 if constexpr (MV2_C3P_ILV == 0) read_p(pbn, 0, IC<0>{});
             } else if constexpr (!ILV) {
                 read_p(pbc, NOFF, IC<NS>{});
@@ -296,13 +315,14 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
 #pragma unroll
             for (int bb = 0; bb < WPOS; ++bb) {
                 Mma<E>::run(wring[SLOT], pset[S_][bb], acc[bb]);
-                if constexpr (ILV) { pset[NS][bb] = *(const i32x4*)(smem + pbc[bb] + NOFF); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (ILV && MV2_C3P_ABL < 4) { pset[NS][bb] = *(const i32x4*)(smem + pbc[bb] + NOFF); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (ILV && MV2_C3P_ABL >= 4) { pset[NS][bb] = pset[S_][bb]; asm volatile("" : "+v"(pset[NS][bb])); }
                 if constexpr (F == 17 && MV2_C3P_ILV != 0) { pset[0][bb] = *(const i32x4*)(smem + pbn[bb]); __builtin_amdgcn_sched_barrier(0); }
             }
             const uint32_t so = G < 18 ? cur_wb + (uint32_t)(G >> 1) * tapstride + (uint32_t)(G & 1) * 1024u
                                        : nxt_wb + (uint32_t)((G - 18) >> 1) * tapstride + (uint32_t)(G & 1) * 1024u;
-            issue_w(so, wring[SLOT]);
-            if constexpr (F < PPW) dma_piece(rs1, so1, par ^ 1, IC<F>{});
+            if constexpr (MV2_C3P_ABL < 3) issue_w(so, wring[SLOT]); else asm volatile("" : "+v"(wring[SLOT]));
+            if constexpr (F < PPW && MV2_C3P_ABL < 1) dma_piece(rs1, so1, par ^ 1, IC<F>{});
             __builtin_amdgcn_sched_barrier(0);
         };
         kstep(IC<0>{}); kstep(IC<1>{}); kstep(IC<2>{}); kstep(IC<3>{}); kstep(IC<4>{}); kstep(IC<5>{});
@@ -653,6 +673,10 @@ int conv3p_launch(const mv2_conv_desc* d, const void* in, size_t in_bytes, const
     pp.per_co = make_fastdiv((uint32_t)d->B * (uint32_t)d->Ti * tiles_sp * (uint32_t)P.splitk);
     pp.S = make_fastdiv((uint32_t)P.splitk); pp.tiles_sp = make_fastdiv(tiles_sp); pp.T = make_fastdiv((uint32_t)d->Ti); pp.tiles_w = make_fastdiv((uint32_t)P.tiles_w);
     pp.grid = (uint32_t)grid;
+    pp.time_inner = 0;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3P_TIME_INNER")) pp.time_inner = atoi(e);
+#endif
     pp.B = d->B; pp.Ti = d->Ti; pp.Hi = d->Hi; pp.Wi = d->Wi; pp.kt = d->kt; pp.nchunk = P.nchunk; pp.splitk = P.splitk; pp.tiles_w_n = P.tiles_w; pp.tiles_h_n = P.tiles_h;
     pp.Ci = d->Ci; pp.co = d->co; pp.co_pad = d->co_pad; pp.out_c = d->out_c; pp.act = d->act; pp.act2 = act2;
     pp.in_bytes = (uint32_t)in_bytes; pp.w_bytes = (uint32_t)w_bytes; pp.ws_bytes = (uint32_t)P.slab_bytes; pp.se_bk = se_bk;
