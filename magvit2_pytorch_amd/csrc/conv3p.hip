@@ -58,6 +58,9 @@ static_assert(18 % RING == 0, "ring slots must divide the 18 fragments of a grou
 #ifndef MV2_C3P_ABL
 #define MV2_C3P_ABL 0
 #endif
+#ifndef MV2_C3P_WDEAD
+#define MV2_C3P_WDEAD 1
+#endif
 constexpr int SLAB = BCO * BPOS * 4;
 constexpr int XCH = 4 * 8192;                                         // exchange region: [wave][2 tiles][4][64 lanes][16 B]
 static_assert(NPIECE == 26 && PPW == 7, "piece bookkeeping below");
@@ -292,6 +295,9 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         const bool live1 = gi + 1 < ge;
         const __amdgpu_buffer_rsrc_t rs1 = live1 ? rs_in : rs_dead;
         const uint32_t so1 = gbase_of(c1, i1);
+        // the weight prefetch past the part's last group is never consumed: it goes through a zero-length descriptor (no memory access, the
+        // ring keeps its instruction count), so the drain behind the loop does not wait for six L2 round trips nobody needs
+        const __amdgpu_buffer_rsrc_t rs_wn = (live1 || MV2_C3P_WDEAD == 0) ? rs_w : __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0, 0x00020000);
         // one k-step: fragment F = 2 tap + s of the group lives in ring slot F % RING (requested RING fragments ago), pset[s] holds
         // its position fragments (read one k-step ago).  The reload of the slot goes out right behind its MFMAs.
         auto kstep = [&](auto f_c) {
@@ -321,7 +327,9 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
             }
             const uint32_t so = G < 18 ? cur_wb + (uint32_t)(G >> 1) * tapstride + (uint32_t)(G & 1) * 1024u
                                        : nxt_wb + (uint32_t)((G - 18) >> 1) * tapstride + (uint32_t)(G & 1) * 1024u;
-            if constexpr (MV2_C3P_ABL < 3) issue_w(so, wring[SLOT]); else asm volatile("" : "+v"(wring[SLOT]));
+            if constexpr (MV2_C3P_ABL >= 3) asm volatile("" : "+v"(wring[SLOT]));
+            else if constexpr (G < 18) issue_w(so, wring[SLOT]);
+            else wring[SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rs_wn, (int)w_voff, (int)so, 0);
             if constexpr (F < PPW && MV2_C3P_ABL < 1) dma_piece(rs1, so1, par ^ 1, IC<F>{});
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -344,15 +352,10 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     C3P_PROF_COUNT(5, 1)
     C3P_PROF_COUNT(6, (unsigned long long)(ge - gb))
 
-    // fused second stage: its operands are requested now (their round trips hide under the exchange): W2 fragments straight from the plain
-    // packed image [row 64][128 B] (lane: row 32 a + l31, chunk 2 ks + hi), bias2 / se_wk for the LDS constants
-    i32x4 w2f[2][4];
+    // fused second stage: bias2 / se_wk for the LDS constants are requested now (their round trip hides under the exchange).  The W2
+    // fragments are NOT (32 registers across the exchange spill: measured 85 -> 88 us per fused launch)
     f32x4 c2v = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FUSED) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w2f[a][ks] = *(const i32x4*)((const char*)p.wp2 + (size_t)(a * 32 + l31) * 128 + (size_t)(2 * ks + hi) * 16);
         if (tid < 16) { if (p.bias2) c2v = *(const f32x4*)(p.bias2 + tid * 4); }
         else if (tid < 32) { if (p.se_wk) c2v = *(const f32x4*)(p.se_wk + (tid - 16) * 4); }
     }
@@ -477,6 +480,12 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         // out[co][pos] = sum_k W2[co][k] * tile[pos][k] for position tile w2 (K = 64 = four k-steps), bias2 + ELU, stores whole rows out of
         // a wave-private LDS tile and writes the SqueezeExcite pooling record of its 2 x 16 strip (conv3.hip's epilogue, unchanged values).
         constexpr int PITCH = ROWP;
+        // W2 fragments straight from the plain packed image [row 64][128 B]: lane (row 32 a + l31, chunk 2 ks + hi)
+        i32x4 w2f[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w2f[a][ks] = *(const i32x4*)((const char*)p.wp2 + (size_t)(a * 32 + l31) * 128 + (size_t)(2 * ks + hi) * 16);
         if (tid < 32) *(f32x4*)(smem + L::kConst2 + tid * 16) = c2v;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
