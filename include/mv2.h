@@ -236,14 +236,6 @@ int mv2_se_pool_fc1(int dtype, const void* y, const float* wk, float bk, const f
  * floats must fit 64 KB of LDS. */
 int mv2_se_rec_fc1(const float* part, const float* w1t, const float* b1, float* hid, int frames, int C, int nchunk,
                    int hidden, int nslice, void* stream);
-/* The tail of the record form in ONE launch (round 4): grid (nslice, frames); a block merges its frame's records, computes ALL hidden units
- * of fc1 itself (w1t read as float4 columns: hidden % 4 == 0), then fc2 + sigmoid for C / nslice channels (a power of 2) and
- * out = gate * y + residual for those channels of every position of the frame.  Results equal mv2_se_rec_fc1 + mv2_se_fc2_apply up to the
- * order of the fp32 sums.  mv2_se_rec_apply_ok() says whether the shape fits (LDS: records + pooled + slab <= 64 KB). */
-int mv2_se_rec_apply_ok(int dtype, int P, int C, int hidden, int nchunk, int nslice);
-int mv2_se_rec_apply(int dtype, const float* part, const float* w1t, const float* b1, const float* w2t, const float* b2,
-                     const void* y, const void* residual, void* out, int frames, int P, int C, int hidden, int nchunk,
-                     int nslice, void* stream);
 int mv2_se_fc2_apply(int dtype, const void* y, const float* hid, const float* w2t, const float* b2,
                      const void* residual, void* out, int frames, int P, int C, int hidden, int nslice,
                      void* stream);

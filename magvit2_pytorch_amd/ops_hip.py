@@ -72,8 +72,6 @@ _SIGS = {
     'mv2_cond_linear': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     'mv2_scale_channels': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     'mv2_se_rec_fc1': (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
-    'mv2_se_rec_apply_ok': (C.c_int, [C.c_int] * 6),
-    'mv2_se_rec_apply': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_void_p]),
     'mv2_pw_se_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     'mv2_pw_se': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.c_int, C.c_void_p]),
@@ -266,14 +264,6 @@ class HipOps:
     def se_rec_fc1(self, part, w1, b1, hid, frames, Cc, nchunk, hidden, nslice):
         fn, args = self.lib.mv2_se_rec_fc1, (_ptr(part), _ptr(w1), _ptr(b1), _ptr(hid), frames, Cc, nchunk, hidden, nslice)
         return _mk(fn, args, 'mv2_se_rec_fc1', (part, w1, b1, hid), [hid])
-
-    def se_rec_apply_ok(self, dt, Pn, Cc, hidden, nchunk, nslice) -> bool:
-        return bool(self.lib.mv2_se_rec_apply_ok(dt, Pn, Cc, hidden, nchunk, nslice))
-
-    def se_rec_apply(self, dt, part, w1, b1, w2, b2, y, residual, out, frames, Pn, Cc, hidden, nchunk, nslice):
-        fn = self.lib.mv2_se_rec_apply
-        args = (dt, _ptr(part), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(y), _ptr(residual), _ptr(out), frames, Pn, Cc, hidden, nchunk, nslice)
-        return _mk(fn, args, 'mv2_se_rec_apply', (part, w1, b1, w2, b2, y, residual, out), [out])
 
     def pw_se_rows(self, dt, rows, Pn, Cc) -> int:
         return int(self.lib.mv2_pw_se_rows(dt, rows, Pn, Cc))

@@ -466,17 +466,9 @@ class Plan:
                 pw_part = (part, nchunk)
                 if two and (nchunk * (C + 3) + C + 1024) * 4 <= 64 * 1024:
                     # small frames: fc1 from the records over hidden-unit slices, then fc2 + apply over channel slices
+                    hid = self.arena.get(frames * hidden, torch.float32)
                     out = Act(self.arena.get(x.rows * C, self.dtype), x.B, x.T, x.H, x.W, C)
                     s1, s2 = hidden // max(16, hidden // 4), C // max(32, C // 8)
-                    if ops.se_rec_apply_ok(self.dt, Pn, C, hidden, nchunk, s2) and not os.environ.get('MV2_SE_TWO'):
-                        # ... in ONE launch: every block computes the whole fc1 itself (the hidden vector never leaves the chip)
-                        steps.append(ops.se_rec_apply(self.dt, part, pm.f32[pre + '.se.w1'], pm.f32[pre + '.se.b1'], pm.f32[pre + '.se.w2'],
-                                                      pm.f32[pre + '.se.b2'], y2.t, x.t, out.t, frames, Pn, C, hidden, nchunk, s2))
-                        self.step_names += ['se_rec_apply']
-                        for t in (part, y2.t, x.t):
-                            self.arena.put(t)
-                        return out
-                    hid = self.arena.get(frames * hidden, torch.float32)
                     steps.append(ops.se_rec_fc1(part, pm.f32[pre + '.se.w1'], pm.f32[pre + '.se.b1'], hid, frames, C, nchunk, hidden, s1))
                     steps.append(ops.se_fc2_apply(self.dt, y2.t, hid, pm.f32[pre + '.se.w2'], pm.f32[pre + '.se.b2'], x.t, out.t,
                                                   frames, Pn, C, hidden, s2))

@@ -545,39 +545,6 @@ class CpuOps:
         step.what = 'se_rec_fc1'
         return step
 
-    def se_rec_apply_ok(self, dt, Pn, Cc, hidden, nchunk, nslice) -> bool:
-        """mirror of mv2_se_rec_apply_ok (misc.hip): shape rules + the LDS budget of the one-launch SqueezeExcite tail"""
-        kvec = 8 if dt == 0 else 4
-        pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
-        if min(Pn, Cc, hidden, nchunk, nslice) <= 0 or Cc % nslice or hidden % 4 or Cc % 4:
-            return False
-        cw, hq = Cc // nslice, hidden // 4
-        if not pow2(cw) or cw > 1024 or cw < kvec or not pow2(hq) or hq > 1024 or hidden > 1024:
-            return False
-        cg = 1024 // hq
-        r4 = lambda v: (v + 3) & ~3
-        lds = (r4(nchunk * (Cc + 2)) + r4(nchunk) + Cc + hidden + cw + max(cg * hidden, 1024)) * 4
-        return lds <= 64 * 1024
-
-    def se_rec_apply(self, dt, part, w1, b1, w2, b2, y, residual, out, frames, Pn, Cc, hidden, nchunk, nslice):
-        """mv2_se_rec_apply: mv2_se_rec_fc1 + mv2_se_fc2_apply in one launch (the hidden vector never leaves the chip)"""
-        def step(stream):
-            pv = part[: frames * nchunk * (Cc + 2)].reshape(frames, nchunk, Cc + 2).to(self.acc)
-            M = pv[:, :, 0].max(dim=1).values
-            w = (pv[:, :, 0] - M[:, None]).exp()
-            S = (pv[:, :, 1] * w).sum(dim=1)
-            pooled = (pv[:, :, 2:] * w[:, :, None]).sum(dim=1) / S[:, None]
-            h = torch.nn.functional.leaky_relu(pooled @ w1.to(self.acc) + b1.to(self.acc), 0.1)
-            g = torch.sigmoid(h @ w2.to(self.acc) + b2.to(self.acc))
-            n = frames * Pn * Cc
-            o = y[:n].reshape(frames, Pn, Cc).to(self.acc) * g[:, None, :]
-            if residual is not None:
-                o = o + residual[:n].reshape(frames, Pn, Cc).to(self.acc)
-            out[:n].copy_(o.reshape(-1).to(out.dtype))
-        step.outs = [out]
-        step.what = 'se_rec_apply'
-        return step
-
     def se_fc2_apply(self, dt, y, hid, w2, b2, residual, out, frames, Pn, Cc, hidden, nslice):
         def step(stream):
             n = frames * Pn * Cc

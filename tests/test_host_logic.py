@@ -322,34 +322,6 @@ def test_squeeze_excite_forms_agree(monkeypatch):
     assert (b_recon - c_recon).abs().mean().item() < 5e-3
 
 
-def test_one_launch_se_tail_is_lowered_and_agrees_with_the_two_launch_form(monkeypatch):
-    """mv2_se_rec_apply (round 4: the small-frame SqueezeExcite tail in one launch) replaces se_rec_fc1 + se_fc2_apply where its shape rule
-    holds; MV2_SE_TWO=1 keeps the two-launch form (so that the lockstep tests can still reach it); both give the same tensors up to the
-    order of the fp32 sums.  The library's shape rule equals its restatement in the emulation."""
-    kw, cfg, sd, v = _full_width_case()
-    tok = emulated_tokenizer(kw, sd, torch.bfloat16)
-    a_codes, a_recon = tok(v, return_codes=True, return_recon=True)
-    names = tok._plan(1, 5)[0].step_names
-    assert 'se_rec_apply' in names and 'se_rec_fc1' not in names
-    monkeypatch.setenv('MV2_SE_TWO', '1')
-    tok2 = emulated_tokenizer(kw, sd, torch.bfloat16)
-    b_codes, b_recon = tok2(v, return_codes=True, return_recon=True)
-    names2 = tok2._plan(1, 5)[0].step_names
-    assert 'se_rec_fc1' in names2 and 'se_rec_apply' not in names2
-    assert torch.equal(a_codes, b_codes) and (a_recon - b_recon).abs().max().item() < 1e-6
-    lib, cpu = ops_hip.load_library(), CpuOps()
-    n = 0
-    for dt in (0, 1):
-        for Pn in (16, 64, 256, 1024):
-            for Cc in (64, 128, 256, 512, 1024, 96):
-                for hidden in (16, 32, 128, 256, 24, 2048):
-                    for nchunk in (1, 2, 8, 32, 64):
-                        for nslice in (1, 2, 4, 8, 3):
-                            assert bool(lib.mv2_se_rec_apply_ok(dt, Pn, Cc, hidden, nchunk, nslice)) == cpu.se_rec_apply_ok(dt, Pn, Cc, hidden, nchunk, nslice), (dt, Pn, Cc, hidden, nchunk, nslice)
-                            n += 1
-    assert n > 1000
-
-
 def test_unsupported_widths_are_rejected_at_construction():
     """widths the kernels cannot run must fail in the constructor with a clear message, not as an opaque
     error code at the first forward."""

@@ -185,17 +185,6 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     run_lockstep(cfg, sd, v, torch.bfloat16)
 
 
-def test_lockstep_two_launch_se_records(monkeypatch):
-    """mv2_se_rec_fc1 + mv2_se_fc2_apply (the form mv2_se_rec_apply replaced in the default lowering) stay in the ABI: compared launch by
-    launch at the real widths with MV2_SE_TWO=1; the default lowering (test_lockstep_full_channel_widths) covers mv2_se_rec_apply."""
-    monkeypatch.setenv('MV2_SE_TWO', '1')
-    kw = dict(image_size=16, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
-    cfg = make_cfg(**kw)
-    sd = init_state_dict(cfg, seed=7, randomize_se=True)
-    v = torch.randn(1, 3, 5, 16, 16, generator=torch.Generator().manual_seed(8))
-    run_lockstep(cfg, sd, v, torch.bfloat16)
-
-
 def test_lockstep_conv_in_8byte_pixels(monkeypatch):
     """conv_in with 4-channel bf16 pixels (8-byte aligned 16-byte gathers): probes the cheaper layout."""
     monkeypatch.setenv('MV2_CONVIN_CPAD', '4')
