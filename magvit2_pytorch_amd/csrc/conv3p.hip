@@ -105,6 +105,8 @@ struct P3Params {
     FastDiv per_co, S, tiles_sp, T, tiles_w;
     uint32_t grid;                        // = gridDim.x (the hidden kernel argument sits in another cache line)
     int32_t time_inner;                   // block order inside a (channel tile, clip): 1 = frames inside spatial tiles, 0 = spatial tiles inside frames
+    int32_t nA, tilesA, SB, tiles_per_xcd; // two-class work list (nA = 0: uniform): per XCD nA class-A blocks = tilesA tiles in `splitk` parts, then tiles in SB parts
+    FastDiv dSB;
     int32_t B, Ti, Hi, Wi, kt, nchunk, splitk, tiles_w_n, tiles_h_n;
     int32_t Ci, co, co_pad, out_c, act, act2;
     uint32_t in_bytes, w_bytes, ws_bytes;
@@ -159,16 +161,33 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
 
     // ---- block -> (channel tile, batch, frame, spatial tile, K part).  XCD-aware: the blocks of one XCD walk one contiguous eighth of
     // the list = few channel tiles, whose weights stay in that XCD's L2, and neighbouring spatial tiles (shared halo borders).
-    uint32_t bid = blockIdx.x;
-    {
+    // Two forms of the work list:
+    //  uniform : every tile in S parts; block id -> (tile, part) after the XCD remap (any grid size);
+    //  two-class (p.nA > 0; host: conv3p_plan): a launch whose tiles fit the chip's workgroup slots ONCE is dispatched in one wave, and
+    //            the dispatcher gives CU i the blocks i, i + CUs, i + 2 CUs (seen in the residency reports): with 2.5 tiles per CU half
+    //            the CUs get three tiles and the launch lasts as long as they do.  Here the first tiles are cut into SA parts, the last
+    //            ones into SB = 2 SA, so that the grid is EXACTLY the slot count and every CU receives the same number of groups (C = 256 at
+    //            batch 1: 512 whole tiles + 128 tiles in halves = 768 blocks, 2.5 tiles per CU).  Per XCD: nA class-A blocks, then the
+    //            class-B blocks; raw block b sits on XCD b % 8 with local index b / 8.  A speed rule only: any placement is correct.
+    uint32_t S, part, r_, q_;
+    const uint32_t tiles_sp = (uint32_t)(p.tiles_h_n * p.tiles_w_n);
+    const uint32_t per_co = (uint32_t)p.B * (uint32_t)T * tiles_sp;      // tiles per channel tile
+    bool classB = false;
+    if (p.nA > 0) {
+        const uint32_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        uint32_t tl;
+        if (local < (uint32_t)p.nA) { S = (uint32_t)p.splitk; tl = fdiv(local, pp.S); part = local - tl * S; }
+        else { classB = true; S = (uint32_t)p.SB; const uint32_t l2 = local - (uint32_t)p.nA; const uint32_t t2 = fdiv(l2, pp.dSB); part = l2 - t2 * S; tl = (uint32_t)p.tilesA + t2; }
+        r_ = xcd * (uint32_t)p.tiles_per_xcd + tl;                        // position in the tile order
+    } else {
+        uint32_t bid = blockIdx.x;
         const uint32_t NW = p.grid, q = NW >> 3, r = NW & 7, xcd = bid & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        S = (uint32_t)p.splitk;
+        q_ = fdiv(bid, pp.S); part = bid - q_ * S; r_ = q_;
     }
-    const uint32_t S = (uint32_t)p.splitk, tiles_sp = (uint32_t)(p.tiles_h_n * p.tiles_w_n);
-    const uint32_t per_co = (uint32_t)p.B * (uint32_t)T * tiles_sp * S;
-    const int co_tile = (int)fdiv(bid, pp.per_co);
-    uint32_t r_ = bid - (uint32_t)co_tile * per_co, q_;
-    q_ = fdiv(r_, pp.S); const uint32_t part = r_ - q_ * S; r_ = q_;
+    const int co_tile = (int)fdiv(r_, pp.per_co);
+    r_ -= (uint32_t)co_tile * per_co;
     // time_inner: the blocks of a spatial tile's T frames are neighbours in the list (and on one XCD), so the three output frames that read
     // an input frame's halo run close together and two of the three reads hit that XCD's L2; otherwise frames are the outer loop
     // (descending, so that the cheap causal-front frames come last and fill the tail).
@@ -187,7 +206,9 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     const uint32_t nparts = min(S, ng);
     if (part >= nparts) return;
     // nparts == S: the group list in S nearly equal ranges; nparts == ng < S: one group per part
-    const int gb = nparts == S ? (int)fdiv(part * ng, pp.S) : (int)part, ge = nparts == S ? (int)fdiv((part + 1) * ng, pp.S) : (int)part + 1;
+    const FastDiv& dS = classB ? pp.dSB : pp.S;
+    const int gb = nparts == S ? (int)fdiv(part * ng, dS) : (int)part, ge = nparts == S ? (int)fdiv((part + 1) * ng, dS) : (int)part + 1;
+    const uint32_t Smax = p.nA > 0 ? (uint32_t)p.SB : S;               // slab slots per tile
     const uint32_t tile_lin = (((uint32_t)co_tile * (uint32_t)p.B + (uint32_t)b) * (uint32_t)T + (uint32_t)t) * tiles_sp + sp;
     const int h0 = thi * TH, w0 = twi * TW;
     const int n0 = co_tile * BCO;
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     if (nparts > 1) {
         const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, p.ws_bytes, 0x00020000);
         const uint32_t inslab = (uint32_t)((cs * 4 + 2 * kh) * 4096 + lane * 16);        // [cs][position tile][4][64 lanes][16 B]
-        const uint32_t soff = (tile_lin * S + part) * (uint32_t)SLAB + inslab;
+        const uint32_t soff = (tile_lin * Smax + part) * (uint32_t)SLAB + inslab;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) own[j][r] = 0.f;
         for (uint32_t q = 0; q < nparts; q += 2) {                // two parts' loads in flight together; odd tail: out of range -> zeros
-            const uint32_t so0 = (tile_lin * S + q) * (uint32_t)SLAB + inslab;
+            const uint32_t so0 = (tile_lin * Smax + q) * (uint32_t)SLAB + inslab;
             const uint32_t so1 = q + 1 < nparts ? so0 + (uint32_t)SLAB : p.ws_bytes;
             i32x4 v0[8], v1[8];
 #pragma unroll
@@ -609,7 +630,8 @@ inline int cus_of_current_device_p() {      // not cached: a process may drive s
 namespace {
 struct Plan3P {
     int tiles_h, tiles_w, nchunk, n_co_tiles, splitk;
-    int64_t M, n_tiles;
+    int nA, tilesA, SB, tiles_per_xcd;      // two-class work list (nA = 0: uniform), see the kernel's block decode
+    int64_t M, n_tiles, grid;
     size_t slab_bytes;
 };
 Plan3P conv3p_plan(const mv2_conv_desc& d);
@@ -643,7 +665,40 @@ Plan3P conv3p_plan(const mv2_conv_desc& d) {
     if (const char* e = getenv("MV2_C3P_S")) { const int v = atoi(e); if (v > 0) s = std::min<int64_t>(v, smax); }
 #endif
     P.splitk = (int)s;
-    P.slab_bytes = P.splitk > 1 ? (size_t)P.n_tiles * P.splitk * SLAB : 0;
+    P.nA = P.tilesA = P.SB = P.tiles_per_xcd = 0;
+    P.grid = P.n_tiles * P.splitk;
+    // Two-class list: the launch fits the slots once (slots / 2 <= tiles < slots) and the slot count is a multiple of 8.  The first
+    // tiles in S0 parts, the last nB tiles in 2 S0 parts, with S0 (tiles + nB) == slots: every CU receives the same number of groups
+    // instead of 3 against 2 tiles (C = 256 at batch 1: S0 = 1, 512 + 128 tiles; C = 512, T = 20: S0 = 2, 256 + 64 tiles).  Only where the
+    // shorter parts keep at least six groups (a part pays ~10k clocks of fixed phases) and every count divides over the 8 XCDs; measured
+    // against the uniform rule in profiles/r04_k3_two_class.log: C = 256 63.6 -> 60.7 us, C = 512 T = 20 65.1 -> 62.1 us.
+    {
+        const int64_t G = (int64_t)P.nchunk * d.kt;
+        int two = 1;
+#ifdef MV2_EXPERIMENTS
+        if (const char* e = getenv("MV2_C3P_TWOCLASS")) two = atoi(e);
+        if (getenv("MV2_C3P_S")) two = 0;
+#endif
+        if (two && slots % 8 == 0 && P.n_tiles < slots && 2 * P.n_tiles >= slots / 4) {
+            for (int64_t s0 = 1; s0 <= 4; ++s0) {
+                if (slots % s0) continue;
+                const int64_t nB = slots / s0 - P.n_tiles, nAt = P.n_tiles - nB;
+                if (nB < 0 || nAt < 0 || nB > P.n_tiles) continue;
+                if (G / (2 * s0) < 6 || nAt % 8 || nB % 8 || P.n_tiles % 8) continue;
+                const int64_t cus = slots / 3;
+                if ((nAt * s0) % cus || (nB * 2 * s0) % cus) continue;      // whole slot layers per class: every CU gets the same mix
+                if ((P.n_tiles * P.splitk) % cus == 0) break;               // the uniform split is balanced already
+                if (nB == 0 && s0 == P.splitk) break;      // the uniform rule already is this split
+                P.splitk = (int)s0; P.SB = (int)(2 * s0);
+                P.tilesA = (int)(nAt / 8); P.nA = (int)(nAt / 8 * s0); P.tiles_per_xcd = (int)(P.n_tiles / 8);
+                P.grid = slots;
+                if (P.nA == 0) { P.nA = 0; P.splitk = P.SB; P.SB = 0; P.grid = P.n_tiles * P.splitk; }      // every tile in class B: a uniform split
+                break;
+            }
+        }
+    }
+    const int smax_used = P.nA > 0 ? P.SB : P.splitk;
+    P.slab_bytes = smax_used > 1 ? (size_t)P.n_tiles * smax_used * SLAB : 0;
     return P;
 }
 }  // namespace
@@ -671,15 +726,16 @@ int conv3p_launch(const mv2_conv_desc* d, const void* in, size_t in_bytes, const
                   const void* wp2, const float* bias2, int act2, const float* se_wk, float se_bk, float* se_part, void* out,
                   void* workspace, size_t workspace_bytes, uint32_t* counters, size_t counter_bytes, hipStream_t st) {
     const Plan3P P = conv3p_plan(*d);
-    const int64_t grid = P.n_tiles * P.splitk;
+    const int64_t grid = P.grid;
     if (P.M >= (int64_t)0x7fffffff || grid >= (int64_t)0x7fffffff || P.slab_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     const size_t w_bytes = (size_t)d->nsteps * d->co_pad * 128;
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     if (P.slab_bytes > 0 && (!workspace || workspace_bytes < P.slab_bytes)) return MV2_EWORKSPACE;
-    if (P.splitk > 1 && (!counters || counter_bytes < (size_t)P.n_tiles * sizeof(uint32_t))) return MV2_EWORKSPACE;
+    if ((P.splitk > 1 || P.nA > 0) && (!counters || counter_bytes < (size_t)P.n_tiles * sizeof(uint32_t))) return MV2_EWORKSPACE;
     const uint32_t tiles_sp = (uint32_t)(P.tiles_h * P.tiles_w);
     P3Params pp{};
-    pp.per_co = make_fastdiv((uint32_t)d->B * (uint32_t)d->Ti * tiles_sp * (uint32_t)P.splitk);
+    pp.per_co = make_fastdiv((uint32_t)d->B * (uint32_t)d->Ti * tiles_sp);
+    pp.nA = P.nA; pp.tilesA = P.tilesA; pp.SB = P.SB; pp.tiles_per_xcd = P.tiles_per_xcd; pp.dSB = make_fastdiv((uint32_t)std::max(P.SB, 1));
     pp.S = make_fastdiv((uint32_t)P.splitk); pp.tiles_sp = make_fastdiv(tiles_sp); pp.T = make_fastdiv((uint32_t)d->Ti); pp.tiles_w = make_fastdiv((uint32_t)P.tiles_w);
     pp.grid = (uint32_t)grid;
     pp.time_inner = 0;
