@@ -14,14 +14,50 @@ decode :1597-1649, decode_from_code_indices :1578-1595, forward (eval branches) 
 """
 from __future__ import annotations
 
+import contextlib
+import dataclasses
 import math
-import os
 from typing import Dict, List, Optional
 
 import torch
 
 from . import pack as P
 from .spec import Stage, parse_layers, se_hidden, ff_inner, has_cond, cond_expanded
+
+
+@dataclasses.dataclass
+class LoweringOptions:
+    """Which kernel form the lowering picks where two exist.  The defaults are the product; the other settings exist so that the lockstep
+    tests reach every kernel form and for A/B timing.  Explicit (``with lowering_options(...)``), never read from the environment: a plan
+    bakes them in when it is built, and a stray variable must not change which kernel runs."""
+    fuse_pw: bool = True           # bf16 C = 64: the unit's 1x1x1 conv + ELU inside mv2_conv3
+    fuse_pool: bool = True         # ... and the SqueezeExcite pooling records from that epilogue
+    pw_se: bool = True             # mv2_pw_se (1x1x1 conv + ELU + pooling records) instead of mv2_conv + a pooling pass
+    se_two_launch: bool = True     # small frames: mv2_se_pool_fc1 / mv2_se_fc2_apply instead of pool / gate / apply
+    conv_rms: bool = True          # RMSNorm folded into the following GEMM (mv2_conv_rms)
+    conv_in: bool = True           # convin.hip instead of the generic gather kernel
+    conv_out: bool = True          # convout.hip instead of the generic gather kernel
+    convin_cpad: int = 4           # channels per input pixel of mv2_video_to_ndhwc (4: 8-byte bf16 pixels, 8: the round-1 layout)
+
+
+OPTIONS = LoweringOptions()
+
+
+@contextlib.contextmanager
+def lowering_options(**kw):
+    """Temporarily replace fields of ``OPTIONS`` (PackedModel / Plan objects built inside the block keep what they read)."""
+    global OPTIONS
+    bad = set(kw) - {fl.name for fl in dataclasses.fields(LoweringOptions)}
+    if bad:
+        raise TypeError(f'unknown lowering option(s): {sorted(bad)}')
+    if 'convin_cpad' in kw and kw['convin_cpad'] not in (4, 8):
+        raise ValueError('convin_cpad must be 4 or 8')
+    prev = OPTIONS
+    OPTIONS = dataclasses.replace(prev, **kw)
+    try:
+        yield OPTIONS
+    finally:
+        OPTIONS = prev
 
 
 PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}      # mv2_pad_ndhwc mode codes (0: no call, the gathers pad with zeros)
@@ -33,7 +69,7 @@ class PackedModel:
         self.dt = P.dtype_code(dtype)
         self.stages: List[Stage] = parse_layers(cfg['layers'], cfg['init_dim'], cfg['max_dim'])
         # 4-channel pixels: 8-byte (bf16) / 16-byte (fp32) rows; 16-byte gathers at 8-byte alignment verified on gfx950
-        self.c_in_pad = int(os.environ.get('MV2_CONVIN_CPAD', '4'))
+        self.c_in_pad = OPTIONS.convin_cpad
         if cfg['channels'] > self.c_in_pad:          # 5 .. 8 input channels: 8-channel pixels (16 bytes in bf16, the round-1 layout)
             self.c_in_pad = 8
         f = lambda k: sd[k].detach().float().cpu()
@@ -217,8 +253,8 @@ class Act:
 def _se_two_launch(Pn, C, hidden, dtype) -> bool:
     """Eligibility of mv2_se_pool_fc1 / mv2_se_fc2_apply (include/mv2.h): a frame of at most 256 KB (the 16x16
     levels: measured 21.5 us against 27 us for pool + gate + apply at C = 512; at 512 KB frames the redundant
-    pooling loses, 40 us against 24 us) and power-of-two widths.  MV2_SE_THREE=1 forces the three-launch form."""
-    if os.environ.get('MV2_SE_THREE'):
+    pooling loses, 40 us against 24 us) and power-of-two widths.  lowering_options(se_two_launch=False) forces the three-launch form."""
+    if not OPTIONS.se_two_launch:
         return False
     es = 2 if dtype == torch.bfloat16 else 4
     pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
@@ -353,7 +389,7 @@ class Plan:
             # (width 16 and above are exact).  Such layers take the separate mv2_rms_rowscale launch.
             es = 2 if self.dtype == torch.bfloat16 else 4
             gather_exact = pc.k_real * es == sum(1 for sgt in pc.seg_taps if not sgt[4]) * pc.seg_bytes
-            if gather_exact and self.ops.conv_rms_ok(d) and not os.environ.get('MV2_NO_CONV_RMS'):
+            if gather_exact and self.ops.conv_rms_ok(d) and OPTIONS.conv_rms:
                 if in_bytes is None:
                     in_bytes = x.t.numel() * x.t.element_size()
                 steps.append(self.ops.conv_rms(d, x.t, in_bytes, pc.wp, segs, pc.bias, None if residual is None else residual.t, out_t))
@@ -445,10 +481,10 @@ class Plan:
         pw_part = None
         if pc3.frag_major:
             # mv2_conv3; bf16 at C = 64 (a workgroup owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
-            fuse = self.dtype == torch.bfloat16 and pc3.co == 64 and pc1.co == pc3.co and pc1.kt == 1 and not os.environ.get('MV2_NO_FUSE_PW')
-            y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and not os.environ.get('MV2_NO_FUSE_POOL') else None))
+            fuse = self.dtype == torch.bfloat16 and pc3.co == 64 and pc1.co == pc3.co and pc1.kt == 1 and OPTIONS.fuse_pw
+            y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and OPTIONS.fuse_pool else None))
             bp = 0
-            if not fuse and (pre + '.k1') in pm.frag and not os.environ.get('MV2_NO_PW_SE'):
+            if not fuse and (pre + '.k1') in pm.frag and OPTIONS.pw_se:
                 bp = ops.pw_se_rows(self.dt, x.rows, Pn, C)
             if fuse:
                 y2 = y1
@@ -660,7 +696,7 @@ class Plan:
             d = dict(dtype=self.dt, B=B, Ti=Tp, Hi=Hp, Wi=Wp, Ci=cp, To=To, Ho=H, Wo=W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1, pt=0, ph=0,
                      pw=0, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=0, act=P.ACT_NONE,
                      store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
-            if name in pm.frag and ops.conv_in_eligible(d) and not os.environ.get('MV2_NO_CONV_IN'):
+            if name in pm.frag and ops.conv_in_eligible(d) and OPTIONS.conv_in:
                 # the halo-staged form (convin.hip): the input frames of a tile go to LDS once instead of one gather per (it, ih) tap
                 y = Act(self.arena.get(B * To * H * W * pc.co, self.dtype), B, To, H, W, pc.co)
                 steps.append(ops.conv_in(d, padded, padded.numel() * padded.element_size(), pm.frag[name], pc.bias, y.t))
@@ -786,7 +822,7 @@ class Plan:
         d = dict(dtype=self.dt, B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1,
                  pt=kt - 1, ph=kh // 2, pw=kw // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=1,
                  act=P.ACT_NONE, store=P.STORE_NCTHW_F32, rt=1, rh=1, rw=1, crop_t=crop_t, out_c=4, splitk=0)
-        if 'conv_out' in pm.frag and self.ops.conv_out_eligible(d) and not os.environ.get('MV2_NO_CONV_OUT'):
+        if 'conv_out' in pm.frag and self.ops.conv_out_eligible(d) and OPTIONS.conv_out:
             # the HBM-stream form (convout.hip): the halo frames of a tile are staged once instead of being gathered once per tap
             steps.append(self.ops.conv_out(d, x.t, x.t.numel() * x.t.element_size(), pm.frag['conv_out'], pc.bias, out_t))
             steps[-1].label = 'conv_out'

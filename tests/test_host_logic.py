@@ -2,6 +2,7 @@
 (executed through the CPU emulation of the kernel semantics, oracle/ndhwc_ops.py), API asserts,
 and that the C-ABI library loads and exports every symbol include/mv2.h declares."""
 import ctypes
+import dataclasses
 import os
 import re
 
@@ -10,6 +11,7 @@ import torch
 
 from magvit2_pytorch_amd import README_LAYERS, VideoTokenizer
 from magvit2_pytorch_amd import ops_hip
+from magvit2_pytorch_amd import plan as plan_mod
 from magvit2_pytorch_amd.spec import init_state_dict, make_cfg, param_specs
 from oracle.ndhwc_ops import CpuOps
 from oracle.restate import OracleTokenizer
@@ -242,7 +244,7 @@ def test_token_shifted_width_8_bf16_takes_the_unfused_rms(monkeypatch):
     fused = [getattr(st, 'label', '') for st in steps if getattr(st, 'what', '') == 'mv2_conv_rms']
     assert not any('qkv' in n or 'ff1' in n for n in fused), fused
     err = (recon - ref_recon).abs().mean().item()
-    monkeypatch.setenv('MV2_NO_CONV_RMS', '1')
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, conv_rms=False))
     tok2 = emulated_tokenizer(kw, sd, torch.bfloat16)
     _, recon2 = tok2(v, return_codes=True, return_recon=True)
     err2 = (recon2 - ref_recon).abs().mean().item()
@@ -309,14 +311,14 @@ def test_squeeze_excite_forms_agree(monkeypatch):
     lowering, bf16 storage: same tensors up to summation order."""
     kw, cfg, sd, v = _full_width_case()
     a_codes, a_recon = emulated_tokenizer(kw, sd, torch.bfloat16)(v, return_codes=True, return_recon=True)
-    monkeypatch.setenv('MV2_SE_THREE', '1')
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, se_two_launch=False))
     tok = emulated_tokenizer(kw, sd, torch.bfloat16)
     names = tok._plan(1, 5)[0].step_names
     assert 'se_pool_fc1' not in names and 'se_gate' in names
     b_codes, b_recon = tok(v, return_codes=True, return_recon=True)
     assert (a_codes != b_codes).float().mean().item() <= 0.02
     assert (a_recon - b_recon).abs().mean().item() < 5e-3
-    monkeypatch.setenv('MV2_NO_FUSE_POOL', '1')
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, se_two_launch=False, fuse_pool=False))
     c_codes, c_recon = emulated_tokenizer(kw, sd, torch.bfloat16)(v, return_codes=True, return_recon=True)
     assert (b_codes != c_codes).float().mean().item() <= 0.02
     assert (b_recon - c_recon).abs().mean().item() < 5e-3
@@ -1049,3 +1051,26 @@ def test_gateloop_time_matches_oracle(vcff, frames):
     v2 = v.clone(); v2[:, :, 5:] += 1.0
     b = tok.encode(v2, video_contains_first_frame=vcff)
     assert torch.equal(a[:, :, :2], b[:, :, :2]) and not torch.equal(a, b)
+
+
+def test_lowering_options_are_explicit_not_environment(monkeypatch):
+    """the lowering reads no environment variable; its switches are the fields of plan.OPTIONS, set through
+    lowering_options(), validated, and restored on exit."""
+    src = open(plan_mod.__file__).read()
+    assert 'os.environ' not in src and 'getenv' not in src
+    for stray in ('MV2_NO_CONV_RMS', 'MV2_NO_CONV_IN', 'MV2_NO_CONV_OUT', 'MV2_SE_THREE', 'MV2_NO_PW_SE', 'MV2_NO_FUSE_PW', 'MV2_TAYLOR_BLOCKS'):
+        monkeypatch.setenv(stray, 'garbage')
+    kw, cfg, sd, v = _full_width_case()
+    names = emulated_tokenizer(kw, sd, torch.bfloat16)._plan(1, 5)[0].step_names
+    before = plan_mod.OPTIONS
+    with plan_mod.lowering_options(se_two_launch=False, pw_se=False) as o:
+        assert not o.se_two_launch and not o.pw_se and o.conv_rms
+        other = emulated_tokenizer(kw, sd, torch.bfloat16)._plan(1, 5)[0].step_names
+    assert plan_mod.OPTIONS is before
+    assert names != other and 'se_gate' in other
+    with pytest.raises(TypeError):
+        with plan_mod.lowering_options(no_such_switch=1):
+            pass
+    with pytest.raises(ValueError):
+        with plan_mod.lowering_options(convin_cpad=5):
+            pass

@@ -13,12 +13,14 @@ Tolerances (stated once, used below):
                the two smooth halves (encoder to the quantizer projection, teacher-forced decoder) carry the regression gates
                (<= 1.10 x the recorded HIP values): test_bf16_drift_within_reference_yardstick.
 """
+import dataclasses
 import os
 
 import pytest
 import torch
 
 from magvit2_pytorch_amd import README_LAYERS, VideoTokenizer
+from magvit2_pytorch_amd import plan as plan_mod
 from magvit2_pytorch_amd.plan import PackedModel, Plan
 from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
 from oracle.ndhwc_ops import CpuOps
@@ -177,7 +179,7 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     """Forces the pool / gate / apply form of SqueezeExcite at every level, so the pooling partials written by the
     fused conv kernel (mv2_conv3 se_part; several 16x16 and 8x16 tiles per frame at 32x32) and mv2_se_pool /
     mv2_se_gate at C = 256 / 512 are all compared launch by launch."""
-    monkeypatch.setenv('MV2_SE_THREE', '1')
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, se_two_launch=False))
     kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
     cfg = make_cfg(**kw)
     sd = init_state_dict(cfg, seed=9, randomize_se=True)
@@ -187,7 +189,7 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
 
 def test_lockstep_conv_in_8byte_pixels(monkeypatch):
     """conv_in with 4-channel bf16 pixels (8-byte aligned 16-byte gathers): probes the cheaper layout."""
-    monkeypatch.setenv('MV2_CONVIN_CPAD', '4')
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, convin_cpad=4))
     g = Golden('small_lfq')
     run_lockstep(g.cfg, g.weights(), g.video(), torch.bfloat16)
 
