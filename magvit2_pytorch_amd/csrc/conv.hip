@@ -344,18 +344,20 @@ MV2_WAITVM(0) MV2_WAITVM(8)
 #undef MV2_WAITVM
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-template <int NS, bool RMS>
+template <int BCO, int BPOS, int WCO, int WPOS, int NS, bool RMS>
 __global__ __launch_bounds__(256, 2) void conv_pw_dma_kernel(const ConvParams p) {
     typedef BF16 E;
-    constexpr int BCO = 128, BPOS = 128, WCO = 2, WPOS = 2;
+    constexpr int NWPOS = BPOS / (32 * WPOS);
+    static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
     constexpr int STAGE = (BCO + BPOS) * 128;
-    constexpr int LPS = (BCO + BPOS) * 8 / 256;                  // DMA loads per thread and step: 4 weight + 4 activation
-    static_assert(NS == 2 || NS == 3, "vmcnt immediates below");      // the library launches NS = 2 (launch_dtype)
+    constexpr int LPW = BCO / 32;                                // DMA loads per thread and step that fetch weight rows ...
+    constexpr int LPS = (BCO + BPOS) / 32;                       // ... and in total (128 x 128: 4 weight + 4 activation)
+    static_assert(NS == 2 || (NS == 3 && LPS == 8), "vmcnt immediates below");      // the library launches NS = 2 (launch_dtype)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const mv2_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave >> 1, wpos = wave & 1;
+    const int wco = wave / NWPOS, wpos = wave % NWPOS;
     int bid = blockIdx.x;
     {   // XCD-aware: blocks of one XCD walk neighbouring tiles (as conv_kernel)
         const int nblk = p.n_co_tiles * p.n_pos_tiles;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_dma_kernel(const ConvParams p)
     for (int i = 0; i < LPS; ++i) {
         const int row = 8 * (wave + 4 * i) + (lane >> 3);
         const uint32_t chunk = (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-        if (i < LPS / 2) voff[i] = (uint32_t)(n0 + row) * 128u + chunk;
+        if (i < LPW) voff[i] = (uint32_t)(n0 + row) * 128u + chunk;
         else {
             const int64_t m = m0 + row - BCO;
             voff[i] = m < p.M ? (uint32_t)m * (uint32_t)d.Ci * 2u + chunk : p.in_bytes;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_dma_kernel(const ConvParams p)
 #pragma unroll
         for (int i = 0; i < LPS; ++i) {
             __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + 8 * (wave + 4 * i) * 128);
-            if (i < LPS / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, (int)(live ? voff[i] : p.w_bytes), (int)so_w, 0, 0);
+            if (i < LPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, (int)(live ? voff[i] : p.w_bytes), (int)so_w, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, (int)(live ? voff[i] : p.in_bytes), (int)so_x, 0, 0);
         }
     };
@@ -536,16 +538,51 @@ inline TileCfg pick_tile(const mv2_conv_desc& d) {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // conv_pw_dma_kernel instead of conv_kernel: bf16 1x1x1 stride-1 un-padded convolutions over whole 128-byte K steps of contiguous input
-// rows, stored through the staged epilogue, with at least 256 tiles of 128 x 128 (one per CU of an MI355X).  Below that the launch is one
-// round of workgroups whose length is the serial chain prologue -> K loop -> epilogue of ONE tile, and the 64 x 64 tiles of conv_kernel
-// (a quarter of that chain, four times the workgroups) win: in-graph A/B on one box (profiles/r03_pw_dma_bench_ab.log), whole step at
-// B = 1: kernel off 2.905 ms, threshold 64: 2.932, 128: 2.922, 256: 2.880; B = 4: 7.90 -> 7.79 ms.  The launch never splits K.
+// rows, stored through the staged epilogue.  The launch never splits K.  Which tile (measured per launch and in the step graph on MI355X,
+// profiles/r04_pw_tile_sweep.log / r04_pw_rule_ab.log; "tiles" below = 128 x 128 tiles of the launch):
+//   GEGLU (value and gate of a packed column pair in one wave):  >= 256 tiles -> 128 x 128 (ff1 C = 256: 39.2 us against 40.0-40.4 with the
+//         smaller tiles, at batch 4 157 against 168); below: conv_kernel, as before;
+//   other epilogues: >= 200 tiles -> 128 x 64 (48 KB of LDS: three workgroups per CU instead of two, half the epilogue chain per tile:
+//         kv 22.5 -> 17.2 us, up-sampling 256 -> 4 x 128: 28.8 -> 21.7, ff2 C = 256: 21.0 -> 18.0, out 13.6 -> 11.1; at batch 4 up-sampling
+//         128 -> 4 x 64: 130 -> 113, ff2 C = 512: 49.6 -> 43.1), 64 x 128 where there are at most 64 output columns;
+//         32 .. 199 tiles -> 64 x 64 (32 KB: five workgroups per CU; the launches the 64 x 64 tiles of conv_kernel used to take: ff2 C = 512
+//         21.5 -> 15.8 us, out 9.0 -> 7.4, time up-sampling 13.1 -> 10.7 / 10.7 -> 8.4, and the T = 5 ff2 that conv_kernel split over K:
+//         15.6 -> 10.3); below 32 tiles: conv_kernel (split-K where K is long).
+// Whole step at B = 1 on one box, two interleaved runs each: 2.689 ms with the round-3 rule (>= 256 tiles -> 128 x 128), 2.635 with
+// ">= 256 -> 128 x 64, >= 96 -> 64 x 64"; B = 4: 7.31 -> 7.23 ms.  Results do not depend on the tile (every output element accumulates its
+// K steps in the same order): bit-identical to conv_kernel's except against its split-K form.
 // A pure function of the descriptor; oracle/ndhwc_ops.py::CpuOps._pw_dma restates it.
-inline bool pw_dma_ok(const mv2_conv_desc& d) {
-    int min_blocks = 256;
+inline bool pw_dma_rule(const mv2_conv_desc& d, int64_t tiles128, TileCfg* t) {
+    if (d.act == MV2_ACT_GEGLU) {
+        if (tiles128 < 256) return false;
+        *t = {128, 128};
+        return true;
+    }
+    if (tiles128 >= 200) { *t = d.co <= 64 ? TileCfg{64, 128} : TileCfg{128, 64}; return true; }
+    if (tiles128 >= 32) { *t = {64, 64}; return true; }
+    return false;
+}
+
+inline bool pw_dma_pick(const mv2_conv_desc& d, TileCfg* tile) {
 #ifdef MV2_EXPERIMENTS
     if (getenv("MV2_TILE")) return false;                                        // tools/k3_bench tile sweep of conv_kernel
-    if (const char* e = getenv("MV2_PW_DMA")) { min_blocks = atoi(e); if (min_blocks <= 0) return false; }   // 0 = off, N = block threshold
+    struct EnvRule { int min_blocks, bco, bpos; } env_rules[8];                  // first entry (descending thresholds) the launch's tile count reaches
+    int nrules = -1;
+    if (const char* e = getenv("MV2_PW_DMA_RULE")) {       // "1024:128x128,256:128x64,96:64x64"; "off" = never
+        nrules = 0;
+        while (*e && nrules < 8) {
+            int mb = 0, a = 0, b2 = 0, n = 0;
+            if (sscanf(e, "%d:%dx%d%n", &mb, &a, &b2, &n) != 3) break;
+            env_rules[nrules++] = {mb, a, b2};
+            e += n; if (*e == ',') ++e;
+        }
+    }
+    if (const char* e = getenv("MV2_PW_DMA")) {            // 0 = off, N = tile threshold of a single rule; tile from MV2_PW_DMA_TILE ("bco,bpos")
+        env_rules[0] = {atoi(e), 128, 128};
+        if (env_rules[0].min_blocks <= 0) return false;
+        if (const char* t = getenv("MV2_PW_DMA_TILE")) sscanf(t, "%d,%d", &env_rules[0].bco, &env_rules[0].bpos);
+        nrules = 1;
+    }
 #endif
     if (d.dtype != MV2_BF16 || d.splitk > 1) return false;
     if (!(d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0 &&
@@ -553,8 +590,25 @@ inline bool pw_dma_ok(const mv2_conv_desc& d) {
     if (d.seg_bytes != 128 || d.Ci % 64 != 0 || d.nsteps != d.Ci / 64) return false;
     if (d.store == MV2_STORE_NCTHW_F32 || (d.out_c * 2) % 16 != 0 || d.co % 8 != 0) return false;                   // stage_ok
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
-    return ((d.co + 127) / 128) * ((M + 127) / 128) >= min_blocks;
+    const int64_t tiles128 = ((d.co + 127) / 128) * ((M + 127) / 128);
+    TileCfg t{0, 0};
+#ifdef MV2_EXPERIMENTS
+    if (nrules >= 0) {
+        for (int i = 0; i < nrules; ++i)
+            if (tiles128 >= env_rules[i].min_blocks) {
+                t = {env_rules[i].bco, env_rules[i].bpos};
+                if (d.act == MV2_ACT_GEGLU && t.bco == 64 && t.bpos == 64) t.bpos = 128;      // value and gate live in one wave: 64 packed columns per wave
+                if (tile) *tile = t;
+                return true;
+            }
+        return false;
+    }
+#endif
+    if (!pw_dma_rule(d, tiles128, &t)) return false;
+    if (tile) *tile = t;
+    return true;
 }
+inline bool pw_dma_ok(const mv2_conv_desc& d) { return pw_dma_pick(d, nullptr); }
 
 struct Launch {
     TileCfg t;
@@ -591,8 +645,8 @@ inline Launch plan_launch(const mv2_conv_desc& d) {
     Launch L;
     L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
-    L.dma = pw_dma_ok(d);
-    L.t = L.dma ? TileCfg{128, 128} : pick_tile(d);
+    L.dma = pw_dma_pick(d, &L.t);
+    if (!L.dma) L.t = pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
     int sk = L.dma ? 1 : d.splitk;
@@ -631,15 +685,28 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
     return MV2_OK;
 }
 
-template <int NS, bool RMS>
+template <int BCO, int BPOS, int WCO, int WPOS, bool RMS>
 int launch_pw_dma(const ConvParams& p, const Launch& L, hipStream_t st) {
-    constexpr size_t lds_main = (size_t)NS * 256 * 128, lds_epi = (size_t)StageCfg<BF16, 128, 128>::kBytes;
+    constexpr int NS = 2;
+    constexpr size_t lds_main = (size_t)NS * (BCO + BPOS) * 128, lds_epi = (size_t)StageCfg<BF16, BCO, BPOS>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    hipError_t e = hipFuncSetAttribute((const void*)conv_pw_dma_kernel<NS, RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv_pw_dma_kernel<NS, RMS>), dim3((unsigned)(L.n_co_tiles * L.n_pos_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS>), dim3((unsigned)(L.n_co_tiles * L.n_pos_tiles)), dim3(256), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
+}
+
+template <bool RMS>
+int launch_pw_dma_tile(const ConvParams& p, const Launch& L, hipStream_t st) {
+    // two stages: 128 x 128 = 64 KB of LDS = two workgroups per CU (measured better than three stages, 96 KB, one workgroup per CU, on every
+    // launch with more than one tile per CU: profiles/r03_pw_dma.log: ff1 22.7 vs 29.9 us, ff2 at B = 4 47.3 vs 50.8); 128 x 64 and
+    // 64 x 128 = 48 KB = three, 64 x 64 = 32 KB = five
+    if (L.t.bco == 128 && L.t.bpos == 128) return launch_pw_dma<128, 128, 2, 2, RMS>(p, L, st);
+    if (L.t.bco == 128 && L.t.bpos == 64) return launch_pw_dma<128, 64, 2, 1, RMS>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 128) return launch_pw_dma<64, 128, 2, 1, RMS>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 64 && p.d.act != MV2_ACT_GEGLU) return launch_pw_dma<64, 64, 1, 1, RMS>(p, L, st);
+    return MV2_EINVAL;
 }
 
 template <typename E>
@@ -647,9 +714,7 @@ int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
     if (L.dma) {
         if constexpr (std::is_same<E, BF16>::value) {
-            // two stages = 64 KB of LDS = two workgroups per CU: measured better than three stages (96 KB, one workgroup per CU) on every
-            // launch with more than one tile per CU (profiles/r03_pw_dma.log: ff1 22.7 vs 29.9 us, ff2 at B = 4 47.3 vs 50.8)
-            return p.rms_fused ? launch_pw_dma<2, true>(p, L, st) : launch_pw_dma<2, false>(p, L, st);
+            return p.rms_fused ? launch_pw_dma_tile<true>(p, L, st) : launch_pw_dma_tile<false>(p, L, st);
         } else {
             return MV2_EINVAL;
         }

@@ -102,7 +102,8 @@ class CpuOps:
 
     @staticmethod
     def _pw_dma(d) -> bool:
-        """mirror of pw_dma_ok (conv.hip): which launches of mv2_conv / mv2_conv_rms run conv_pw_dma_kernel (128 x 128 tiles, no split-K)"""
+        """mirror of pw_dma_pick / pw_dma_rule (conv.hip): which launches of mv2_conv / mv2_conv_rms run conv_pw_dma_kernel (no split-K;
+        the tile - 128 x 128 for GEGLU, 128 x 64 / 64 x 128 / 64 x 64 otherwise - does not change results)"""
         if d['dtype'] != 0 or d.get('splitk', 0) > 1:
             return False
         if not (d['kt'] == d['kh'] == d['kw'] == 1 and d['st'] == d['sh'] == d['sw'] == 1 and d['pt'] == d['ph'] == d['pw'] == 0
@@ -113,7 +114,8 @@ class CpuOps:
         if d['store'] == STORE_NCTHW_F32 or (d['out_c'] * 2) % 16 != 0 or d['co'] % 8 != 0:
             return False
         M = d['B'] * d['To'] * d['Ho'] * d['Wo']
-        return -(-d['co'] // 128) * -(-M // 128) >= 256
+        tiles128 = -(-d['co'] // 128) * -(-M // 128)
+        return tiles128 >= (256 if d['act'] == ACT_GEGLU else 32)
 
     def conv_rms_ok(self, d) -> bool:
         """mirror of mv2_conv_rms_ok (conv.hip): staged-store shapes whose launch plan keeps the reduction in one workgroup.  The

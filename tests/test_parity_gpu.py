@@ -428,13 +428,16 @@ def test_pw_se_kernel_vs_emulation(C, frames, P):
     assert torch.allclose(pg[:, 1] * pg[:, 0].exp(), pc_[:, 1] * pc_[:, 0].exp(), rtol=2e-2)
 
 
-@pytest.mark.parametrize('case', ['rows_residual', 'geglu_rms', 'shuffle_silu', 'long_k_residual', 'edge_256_rms', 'rows_rowscale_lrelu', 'below_threshold'])
+@pytest.mark.parametrize('case', ['rows_residual', 'geglu_rms', 'shuffle_silu', 'long_k_residual', 'edge_256_rms', 'rows_rowscale_lrelu', 'small_tiles_long_k',
+                                  'small_tiles_rms', 'narrow_output', 'geglu_below_threshold', 'tiny_launch'])
 def test_pointwise_dma_kernel_vs_emulation(case):
     """conv_pw_dma_kernel (conv.hip: both GEMM operands global -> LDS by buffer_load ... lds, hand-placed waits) behind mv2_conv /
-    mv2_conv_rms against the emulation: plain rows + residual with a ragged last tile, GEGLU with the RMSNorm row scale computed in the
-    launch, depth-to-space store + SiLU (the up-sampling conv), a 22-step K loop, exactly 256 tiles (the threshold) with the row scale, a
-    caller-supplied row scale + residual + leaky ReLU on a ragged launch (the AdaptiveRMSNorm / discriminator forms);
-    the last case has 160 tiles and stays on conv_kernel (the rule is checked on both sides: library and its restatement)."""
+    mv2_conv_rms against the emulation, every tile of the rule (pw_dma_rule): 128 x 64 - plain rows + residual with a ragged last tile,
+    depth-to-space store + SiLU (the up-sampling conv), a 22-step K loop, 256 tiles with the row scale computed in the launch, a
+    caller-supplied row scale + residual + leaky ReLU on a ragged launch (the AdaptiveRMSNorm / discriminator forms); 128 x 128 - GEGLU with
+    the in-launch row scale; 64 x 64 - 160 tiles with a 22-step K loop (conv_kernel's launch until round 4), 60 tiles with the in-launch row
+    scale; 64 x 128 - a 64-column output.  GEGLU below 256 tiles and a 4-tile launch stay on conv_kernel (the rule is checked on both
+    sides: library and its restatement)."""
     from magvit2_pytorch_amd import pack as PK
     from magvit2_pytorch_amd.ops_hip import HipOps
     ops, cpu = HipOps('cuda:0'), CpuOps()
@@ -446,7 +449,11 @@ def test_pointwise_dma_kernel_vs_emulation(case):
         'long_k_residual': (32, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, True),    # 64 x 4 = 256 tiles, 22 steps
         'edge_256_rms': (16, 32, 32, 640, 256, PK.ACT_ELU, PK.STORE_ROWS, (1, 1, 1), False, True, True),         # 128 x 2 = 256 tiles, 10 steps
         'rows_rowscale_lrelu': (5, 60, 60, 192, 256, PK.ACT_LRELU, PK.STORE_ROWS, (1, 1, 1), True, 'given', True),  # 141 x 2 tiles, ragged; the caller's row scale
-        'below_threshold': (20, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, False),   # 40 x 4 = 160 tiles: conv_kernel
+        'small_tiles_long_k': (20, 16, 16, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, True),  # 40 x 4 = 160 tiles of 128: 64 x 64 tiles
+        'small_tiles_rms': (5, 16, 15, 512, 768, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), False, True, True),         # 10 x 6 = 60 tiles, ragged (1200 rows): 64 x 64, row scale in the launch
+        'narrow_output': (25, 32, 32, 128, 64, PK.ACT_ELU, PK.STORE_ROWS, (1, 1, 1), True, False, True),            # 200 x 1 tiles, 64 columns: 64 x 128 tiles
+        'geglu_below_threshold': (5, 16, 16, 512, 2 * 1408, PK.ACT_GEGLU, PK.STORE_ROWS, (1, 1, 1), False, True, False),   # 10 x 22 = 220 tiles: conv_kernel
+        'tiny_launch': (2, 8, 8, 1408, 512, PK.ACT_NONE, PK.STORE_ROWS, (1, 1, 1), True, False, False),             # 1 x 4 tiles: conv_kernel (split-K)
     }[case]
     M = T * H * W
     w2d = torch.randn(co_ref, Ci, generator=g) / Ci ** 0.5
@@ -471,7 +478,8 @@ def test_pointwise_dma_kernel_vs_emulation(case):
     assert not ops.conv_pointwise_dma(dict(d, dtype=PK.MV2_F32)) and not ops.conv_pointwise_dma(dict(d, splitk=2))
     if rms:
         assert ops.conv_rms_ok(d) and cpu.conv_rms_ok(d)
-    assert ops.conv_workspace_bytes(d) == 0
+    wsb = ops.conv_workspace_bytes(d)
+    assert wsb == 0 or not dma                      # the LDS-DMA kernel never splits K
     x = torch.randn(M * Ci, generator=g).to(torch.bfloat16)
     n_out = M * rt * rh * rw * out_c
     r = torch.randn(n_out, generator=g).to(torch.bfloat16) if res else None
@@ -486,7 +494,8 @@ def test_pointwise_dma_kernel_vs_emulation(case):
     else:
         rs = (torch.rand(M, generator=g) + 0.5) if given else None
         cpu.conv(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, rs, r, out_c_, None)(None)
-        ops.conv(d, xg, x.numel() * 2, wg, segs_g, bg, None if rs is None else rs.to(dev), rg, out_g, None)(ops.current_stream())
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ops.conv(d, xg, x.numel() * 2, wg, segs_g, bg, None if rs is None else rs.to(dev), rg, out_g, ws)(ops.current_stream())
     ops.synchronize()
     a, b = out_g.cpu().float(), out_c_.float()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()

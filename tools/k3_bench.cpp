@@ -376,8 +376,9 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
 // generic mv2_conv (conv.hip) on a 1x1x1 convolution = plain GEMM rows x Ci -> Co: timing + phase clocks
 typedef int (*convrms_fn)(const mv2_conv_desc*, const void*, size_t, const void*, const mv2_seg*, const float*, const void*, void*, void*);
 static convrms_fn p_conv_rms = nullptr;
+static bool g_pw_quiet = false;
 static float time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st, bool rms = false, int shuf = 1,
-                            std::vector<uint16_t>* keep = nullptr) {
+                            std::vector<uint16_t>* keep = nullptr, int shuf_t = 1) {
     typedef int (*setprof_fn2)(void*);
     static setprof_fn2 p_cvprof = nullptr; static bool looked = false;
     if (!looked) { looked = true; p_cvprof = (setprof_fn2)dlsym(RTLD_DEFAULT, "mv2_conv_set_profile"); }
@@ -387,6 +388,7 @@ static float time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, i
     d.st = d.sh = d.sw = 1; d.kt = d.kh = d.kw = 1; d.nsteps = nsteps; d.seg_bytes = 128; d.check_bounds = 0; d.act = act; d.store = MV2_STORE_ROWS;
     d.rt = d.rh = d.rw = 1; d.out_c = act == MV2_ACT_GEGLU ? Co / 2 : Co;
     if (shuf > 1) { d.store = MV2_STORE_SHUFFLE; d.rh = d.rw = shuf; d.out_c = Co / (shuf * shuf); }
+    if (shuf_t > 1) { d.store = MV2_STORE_SHUFFLE; d.rt = shuf_t; d.out_c = Co / shuf_t; }
     const size_t M = (size_t)rows_t * rows_hw * rows_hw;
     rng_state = 12345u;                                  // same operands on every call (ab_pointwise compares two runs)
     std::vector<uint16_t> hin(M * Ci), hw((size_t)nsteps * co_pad * 64);
@@ -394,7 +396,7 @@ static float time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, i
     std::vector<mv2_seg> segs(nsteps); for (int i = 0; i < nsteps; ++i) { segs[i].elem_offset = i * 64; segs[i].sel = 1u | (1u << 8) | (1u << 16); }
     std::vector<float> bias(co_pad, 0.01f);
     void *din = to_dev(hin.data(), hin.size() * 2), *dw = to_dev(hw.data(), hw.size() * 2), *dsegs = to_dev(segs.data(), segs.size() * 8), *dbias = to_dev(bias.data(), bias.size() * 4);
-    const size_t out_elems = M * (size_t)d.out_c * d.rh * d.rw;
+    const size_t out_elems = M * (size_t)d.out_c * d.rh * d.rw * d.rt;
     void *dout, *dres; CK(hipMalloc(&dout, out_elems * 2)); CK(hipMalloc(&dres, out_elems * 2)); CK(hipMemset(dres, 0, out_elems * 2)); CK(hipMemset(dout, 0xff, out_elems * 2));
     const size_t wsb = p_conv_ws(&d); void* dws; CK(hipMalloc(&dws, wsb ? wsb : 16));
     auto run = [&] {
@@ -405,8 +407,8 @@ static float time_pointwise(const char* name, int rows_t, int rows_hw, int Ci, i
     if (keep) { keep->resize(out_elems); CK(hipMemcpy(keep->data(), dout, out_elems * 2, hipMemcpyDeviceToHost)); }
     const float t = time_us(run, 20, st);
     const double gf = 2.0 * M * Ci * (double)Co * 1e-9;
-    printf("== generic %-22s M=%zu Ci=%d Co=%d: %7.1f us (%5.0f TF/s)  split-K ws %.1f MB\n", name, M, Ci, Co, t, gf / t * 1e3, wsb / 1048576.0);
-    if (p_cvprof) {
+    if (!g_pw_quiet) printf("== generic %-22s M=%zu Ci=%d Co=%d: %7.1f us (%5.0f TF/s)  split-K ws %.1f MB\n", name, M, Ci, Co, t, gf / t * 1e3, wsb / 1048576.0);
+    if (p_cvprof && !g_pw_quiet) {
         unsigned long long* dprof; const int NB = 8192; CK(hipMalloc((void**)&dprof, NB * 64)); CK(hipMemset(dprof, 0, NB * 64));
         p_cvprof(dprof); run(); CK(hipStreamSynchronize(st)); p_cvprof(nullptr);
         std::vector<unsigned long long> hp(NB * 8); CK(hipMemcpy(hp.data(), dprof, NB * 64, hipMemcpyDeviceToHost));
@@ -439,6 +441,37 @@ static void ab_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int 
            a.size() != b.size() ? "  SIZE MISMATCH" : "");
 }
 
+// conv_pw_dma_kernel tile sweep (experiments library: MV2_PW_DMA_TILE): the library's rule (whatever kernel it picks), the generic kernel,
+// then the LDS-DMA kernel forced on with each tile; every output compared element-wise with the generic kernel's
+static void sweep_pointwise(const char* name, int rows_t, int rows_hw, int Ci, int Co, int act, bool residual, hipStream_t st, bool rms = false, int shuf = 1, int shuf_t = 1) {
+    g_pw_quiet = true;
+    std::vector<uint16_t> ref, b;
+    unsetenv("MV2_PW_DMA"); unsetenv("MV2_PW_DMA_TILE");
+    const float trule = time_pointwise(name, rows_t, rows_hw, Ci, Co, act, residual, st, rms, shuf, nullptr, shuf_t);
+    setenv("MV2_PW_DMA", "0", 1);
+    const float t0 = time_pointwise(name, rows_t, rows_hw, Ci, Co, act, residual, st, rms, shuf, &ref, shuf_t);
+    printf("## %-28s rule %6.1f | generic %6.1f |", name, trule, t0);
+    const char* tiles[] = {"128,128", "128,64", "64,128", "64,64"};
+    setenv("MV2_PW_DMA", "1", 1);
+    for (const char* tl : tiles) {
+        setenv("MV2_PW_DMA_TILE", tl, 1);
+        const float t1 = time_pointwise(name, rows_t, rows_hw, Ci, Co, act, residual, st, rms, shuf, &b, shuf_t);
+        size_t diff = 0, nan = 0; double maxd = 0;
+        for (size_t i = 0; i < ref.size() && i < b.size(); ++i) {
+            const float x = bf2f(ref[i]), y = bf2f(b[i]);
+            if (!(y == y)) ++nan;
+            if (ref[i] != b[i]) { ++diff; maxd = std::max(maxd, (double)fabsf(x - y)); }
+        }
+        printf(" %s %6.1f", tl, t1);
+        if (t1 < 0 || ref.size() != b.size() || nan || (diff && !rms) || (rms && maxd > 0.07)) printf(" [BAD diff %zu maxd %.3g nan %zu]", diff, maxd, nan);
+        else if (diff) printf(" (d%zu %.2g)", diff, maxd);
+        printf(" |");
+    }
+    printf("\n");
+    unsetenv("MV2_PW_DMA"); unsetenv("MV2_PW_DMA_TILE");
+    g_pw_quiet = false;
+}
+
 int main(int argc, char** argv) {
     std::string lib = argc > 1 ? argv[1] : "magvit2_pytorch_amd/libmv2_hip_exp.so";
     void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
@@ -450,6 +483,43 @@ int main(int argc, char** argv) {
     if (p_setprof_old || p_setprof_new) p_setprof = set_both_profiles;
     printf("conv3 kernel under test: MV2_C3_KERNEL=%s\n", getenv("MV2_C3_KERNEL") ? getenv("MV2_C3_KERNEL") : "(library rule)");
     if (!p_conv3 || !p_c3_ws || !p_c3_cnt || !p_c3_tiles) { printf("missing mv2_conv3 symbols\n"); return 2; }
+    if (argc > 2 && !strcmp(argv[2], "pwtile")) {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        p_conv_rms = (convrms_fn)dlsym(h, "mv2_conv_rms");
+        if (!p_conv_rms) { printf("no mv2_conv_rms\n"); return 2; }
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("---- pass %d: every pointwise launch of BASELINE configs[1] (B = 1), us per launch\n", rep);
+            sweep_pointwise("enc5 ff1 C=256 geglu+rms", 20, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2, true);
+            sweep_pointwise("enc5 ff2 C=256 +res", 20, 32, 704, 256, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("enc5 q C=256 rms", 20, 32, 256, 256, MV2_ACT_NONE, false, st2, true);
+            sweep_pointwise("enc5 kv C=256 rms", 20, 32, 256, 512, MV2_ACT_NONE, false, st2, true);
+            sweep_pointwise("enc5 out C=256 +res", 20, 32, 256, 256, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("enc8 ff1 C=512 T=20 geglu+rms", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+            sweep_pointwise("enc8 ff2 C=512 T=20 +res", 20, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("enc8 qkv C=512 T=20 rms", 20, 16, 512, 768, MV2_ACT_NONE, false, st2, true);
+            sweep_pointwise("enc8 out C=512 T=20 +res", 20, 16, 256, 512, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("enc13 ff2 C=512 T=5 +res", 5, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("enc13 out C=512 T=5 +res", 5, 16, 256, 512, MV2_ACT_NONE, true, st2);
+            sweep_pointwise("dec12 up 128->4x64 64x64", 20, 64, 128, 256, MV2_ACT_SILU, false, st2, false, 2);
+            sweep_pointwise("dec10 up 256->4x128 32x32", 20, 32, 256, 512, MV2_ACT_SILU, false, st2, false, 2);
+            sweep_pointwise("dec7 up 512->4x256 16x16", 20, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 2);
+            sweep_pointwise("dec4 time-up 512->2x512 T=10", 10, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 1, 2);
+            sweep_pointwise("dec2 time-up 512->2x512 T=5", 5, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 1, 2);
+            sweep_pointwise("ragged M=20x29x29 +res", 20, 29, 704, 256, MV2_ACT_NONE, true, st2);
+        }
+        printf("---- batch 4\n");
+        sweep_pointwise("B4 ff1 C=256 geglu+rms", 80, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2, true);
+        sweep_pointwise("B4 ff2 C=256 +res", 80, 32, 704, 256, MV2_ACT_NONE, true, st2);
+        sweep_pointwise("B4 kv C=256 rms", 80, 32, 256, 512, MV2_ACT_NONE, false, st2, true);
+        sweep_pointwise("B4 ff1 C=512 T=20 geglu+rms", 80, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        sweep_pointwise("B4 ff2 C=512 T=20 +res", 80, 16, 1408, 512, MV2_ACT_NONE, true, st2);
+        sweep_pointwise("B4 qkv C=512 T=20 rms", 80, 16, 512, 768, MV2_ACT_NONE, false, st2, true);
+        sweep_pointwise("B4 ff1 C=512 T=5 geglu+rms", 20, 16, 512, 2 * 1408, MV2_ACT_GEGLU, false, st2, true);
+        sweep_pointwise("B4 dec12 up 128->4x64", 80, 64, 128, 256, MV2_ACT_SILU, false, st2, false, 2);
+        sweep_pointwise("B4 dec10 up 256->4x128", 80, 32, 256, 512, MV2_ACT_SILU, false, st2, false, 2);
+        sweep_pointwise("B4 dec7 up 512->4x256", 80, 16, 512, 1024, MV2_ACT_SILU, false, st2, false, 2);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "pwdma")) {
         hipStream_t st2; CK(hipStreamCreate(&st2));
         p_conv_rms = (convrms_fn)dlsym(h, "mv2_conv_rms");
