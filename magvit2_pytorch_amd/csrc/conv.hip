@@ -524,7 +524,7 @@ inline TileCfg pick_tile(const mv2_conv_desc& d) {
 #endif
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     const int64_t blocks128 = ((d.co + 127) / 128) * ((M + 127) / 128);
-    const bool small = small_policy > 0 && d.co >= 64 && blocks128 < (int64_t)(small_policy >= 2 ? 2 : 1) * device_cus();
+    const bool small = small_policy > 0 && d.co >= 64 && blocks128 < (int64_t)small_policy * device_cus();      // product: fewer than 2 tiles per CU
     if (d.act == MV2_ACT_GEGLU) {
         if (d.co <= 64) return {64, 256};
         return small ? TileCfg{64, 128} : TileCfg{128, 128};
