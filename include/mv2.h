@@ -111,8 +111,9 @@ typedef struct mv2_conv_desc {
 
 size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d);
 /* 1 when mv2_conv / mv2_conv_rms run this descriptor on the LDS-DMA pointwise kernel (conv.hip conv_pw_dma_kernel: bf16, 1x1x1, stride 1,
- * un-padded, whole 128-byte K steps, staged stores, >= 256 tiles of 128 x 128): same operands, same results, never splits K.  Introspection
- * for tests and profiles; callers need not ask. */
+ * un-padded, whole 128-byte K steps, staged stores; GEGLU launches from 256 tiles of 128 x 128 on, every other epilogue from 32 on - the
+ * kernel's own tile is 128 x 128 / 128 x 64 / 64 x 128 / 64 x 64 by launch size): same operands, same results, never splits K.
+ * Introspection for tests and profiles; callers need not ask. */
 int mv2_conv_pointwise_dma(const mv2_conv_desc* d);
 int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
              const float* bias, const float* rowscale, const void* residual, void* out,
