@@ -122,11 +122,13 @@ template <> struct Act<F32> {
 };
 template <> struct Act<BF16> {
     static __device__ __forceinline__ float elu(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
-    static __device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+    // v_rcp_f32 (1 ulp) instead of a division: without fast-math __fdividef compiles to the full IEEE sequence (2 v_div_scale, v_rcp, Newton
+    // steps, v_div_fmas, v_div_fixup: ~10 VALU slots per value in an epilogue whose wave has the SIMD to itself)
+    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
     static __device__ __forceinline__ float gelu(float v) {
         // erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), far below bf16 resolution
         const float x = fabsf(v) * 0.70710678118654752440f;
-        const float t = __fdividef(1.f, 1.f + 0.3275911f * x);
+        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
         const float erf_abs = 1.f - poly * __expf(-x * x);
         const float erfv = v < 0.f ? -erf_abs : erf_abs;
