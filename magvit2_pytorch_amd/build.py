@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, 'libmv2_hip.so')
 SOURCES = ['conv.hip', 'conv3.hip', 'conv3p.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
 # experiments library (tools/ only, -DMV2_EXPERIMENTS): the same sources with phase-clock profiling and the conv3 work-split knobs
 LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
-SOURCES_EXP = SOURCES + ['exp_se.hip']      # + kernels that exist only to be measured (tools/)
+SOURCES_EXP = SOURCES + ['exp_se.hip', 'exp_attn.hip']      # + kernels that exist only to be measured (tools/)
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv3p.h'),
            os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
