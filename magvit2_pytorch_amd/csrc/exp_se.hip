@@ -168,3 +168,163 @@ extern "C" int mv2x_se_gate_apply(int dtype, const float* part, const float* w1t
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// ---- se_gate_kernel with its independent global loads hoisted in front of the first reduction (same sums, value for value): how much of the
+// 8.5 us per launch is exposed L2 round trips?  tools/se_fuse_bench.cpp times it against mv2_se_gate and compares the gates bit for bit.
+__global__ __launch_bounds__(1024) void se_gate_v2_kernel(const float* __restrict__ part, const float* __restrict__ w1t,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                       int hidden, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pooled = sm;               // C
+    float* hid = pooled + C;          // hidden
+    float* wj = hid + hidden;         // nchunk: exp(m_j - M)
+    float* red = wj + nchunk;         // 32 scratch
+    float* slab = red + 32;           // 1024 partial sums
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pf = part + (int64_t)f * nchunk * (C + 2);
+    // ---- v2: every global load whose ADDRESS does not depend on an earlier result is issued here, before the first reduction: the first
+    // batch of record sums (needs only wj later), of w1t and of w2t.  The arithmetic below is se_gate_kernel's, value for value.
+    const int JSp = max(1, 1024 / C), cp = tid % C, jsp = tid / C;
+    float vpre[8];
+    const bool have_v = jsp < JSp && jsp + 7 * JSp < nchunk;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vpre[u] = have_v ? pf[(int64_t)(jsp + u * JSp) * (C + 2) + 2 + cp] : 0.f;
+    const int KSp = max(1, 1024 / hidden), kp = tid % hidden, csp = tid / hidden, perp = (C + KSp - 1) / KSp;
+    const int c0p = csp * perp, c1p = min(C, c0p + perp);
+    float w1pre[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w1pre[u] = (csp < KSp && c0p + u < c1p) ? w1t[(int64_t)(c0p + u) * hidden + kp] : 0.f;
+    const int GSp = max(1, 1024 / C), c2p = tid % C, ksp = tid / C, per2p = (hidden + GSp - 1) / GSp;
+    const int k0p = ksp * per2p, k1p = min(hidden, k0p + per2p);
+    float w2pre[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w2pre[u] = (ksp < GSp && k0p + u < k1p) ? w2t[(int64_t)(k0p + u) * C + c2p] : 0.f;
+    float m = -INFINITY;
+    for (int j = tid; j < nchunk; j += 1024) m = fmaxf(m, pf[(int64_t)j * (C + 2)]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, red[w]);
+    float s = 0.f;
+    for (int j = tid; j < nchunk; j += 1024) {
+        const float mj = pf[(int64_t)j * (C + 2)];
+        const float w = (mj == -INFINITY) ? 0.f : expf(mj - M);
+        wj[j] = w;
+        s += pf[(int64_t)j * (C + 2) + 1] * w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[16 + wave] = s;
+    __syncthreads();
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) S += red[16 + w];
+    const float inv_s = 1.f / S;
+    {   // pooled[c]: threads (c, j-slice)
+        const int JS = max(1, 1024 / C);
+        const int c = tid % C, js = tid / C;
+        if (js < JS) {
+            float a = 0.f;
+            int j = js;
+            bool firstv = true;
+            for (; j + 7 * JS < nchunk; j += 8 * JS) {             // eight loads in flight (the plain loop was a chain of L2 latencies)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = firstv ? vpre[u] : pf[(int64_t)(j + u * JS) * (C + 2) + 2 + c];
+                firstv = false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u] * wj[j + u * JS];
+            }
+            for (; j < nchunk; j += JS) a += pf[(int64_t)j * (C + 2) + 2 + c] * wj[j];
+            slab[js * C + c] = a;
+        }
+        __syncthreads();
+        if (tid < C) {
+            float a = 0.f;
+            for (int q = 0; q < JS; ++q) a += slab[q * C + tid];
+            pooled[tid] = a * inv_s;
+        }
+        __syncthreads();
+    }
+    {   // hidden[k]: threads (k, c-slice)
+        const int KS = max(1, 1024 / hidden);
+        const int k = tid % hidden, cs = tid / hidden;
+        const int per = (C + KS - 1) / KS;
+        if (cs < KS) {
+            const int c0 = cs * per, c1 = min(C, c0 + per);
+            float a0 = 0.f, a1 = 0.f;
+            int c = c0;
+            bool first1 = true;
+            for (; c + 16 <= c1; c += 16) {          // 16 independent loads in flight per thread
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = first1 ? w1pre[u] : w1t[(int64_t)(c + u) * hidden + k];
+                first1 = false;
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { a0 += w[u] * pooled[c + u]; a1 += w[u + 1] * pooled[c + u + 1]; }
+            }
+            if (c < c1) {                                            // tail (< 16): still one batch of independent loads
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = first1 ? w1pre[u] : ((c + u < c1) ? w1t[(int64_t)(c + u) * hidden + k] : 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a0 += (c + u < c1) ? w[u] * pooled[c + u] : 0.f;
+            }
+            slab[cs * hidden + k] = a0 + a1;
+        }
+        __syncthreads();
+        if (tid < hidden) {
+            float a = b1[tid];
+            for (int q = 0; q < KS; ++q) a += slab[q * hidden + tid];
+            hid[tid] = a > 0.f ? a : 0.1f * a;
+        }
+        __syncthreads();
+    }
+    {   // gate[c]: threads (c, k-slice)
+        const int GS = max(1, 1024 / C);
+        const int c = tid % C, ks = tid / C;
+        const int per = (hidden + GS - 1) / GS;
+        if (ks < GS) {
+            const int k0 = ks * per, k1 = min(hidden, k0 + per);
+            float a0 = 0.f, a1 = 0.f;
+            int k = k0;
+            bool first2 = true;
+            for (; k + 16 <= k1; k += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = first2 ? w2pre[u] : w2t[(int64_t)(k + u) * C + c];
+                first2 = false;
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { a0 += w[u] * hid[k + u]; a1 += w[u + 1] * hid[k + u + 1]; }
+            }
+            if (k < k1) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = first2 ? w2pre[u] : ((k + u < k1) ? w2t[(int64_t)(k + u) * C + c] : 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a0 += (k + u < k1) ? w[u] * hid[k + u] : 0.f;
+            }
+            slab[ks * C + c] = a0 + a1;
+        }
+        __syncthreads();
+        if (tid < C) {
+            float a = b2[tid];
+            for (int q = 0; q < GS; ++q) a += slab[q * C + tid];
+            gate[(int64_t)f * C + tid] = 1.f / (1.f + expf(-a));
+        }
+    }
+}
+
+
+extern "C" int mv2x_se_gate_v2(const float* part, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                               float* gate, int frames, int C, int hidden, int nchunk, void* stream) {
+    if (!part || !w1t || !b1 || !w2t || !b2 || !gate || frames <= 0 || nchunk <= 0) return MV2_EINVAL;
+    if (C <= 0 || C > 1024 || hidden <= 0 || hidden > 1024) return MV2_EINVAL;
+    const size_t lds = (size_t)(C + hidden + nchunk + 32 + 1024) * sizeof(float);
+    if (lds > 64 * 1024) return MV2_EINVAL;
+    hipLaunchKernelGGL(se_gate_v2_kernel, dim3((unsigned)frames), dim3(1024), lds, (hipStream_t)stream, part, w1t, b1, w2t, b2, gate, C, hidden, nchunk);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

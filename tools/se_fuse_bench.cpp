@@ -32,13 +32,15 @@ int main(int argc, char** argv) {
     if (!h) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     gate_fn p_gate = (gate_fn)dlsym(h, "mv2_se_gate"); apply_fn p_apply = (apply_fn)dlsym(h, "mv2_se_apply"); fused_fn p_fused = (fused_fn)dlsym(h, "mv2x_se_gate_apply");
     if (!p_gate || !p_apply || !p_fused) { printf("missing symbols (experiments library?)\n"); return 2; }
+    gate_fn p_gate2 = (gate_fn)dlsym(h, "mv2x_se_gate_v2");
+    const bool gate_only = argc > 2 && !strcmp(argv[2], "gate");
     hipStream_t st; CK(hipStreamCreate(&st));
     struct Shp { const char* name; int frames, P, C, nchunk; };
     const Shp shapes[] = {{"C=64 128x128 (conv3 records)", 20, 16384, 64, 512}, {"C=128 64x64", 20, 4096, 128, 64}, {"C=256 32x32", 20, 1024, 256, 32},
                           {"B4 C=64 128x128", 80, 16384, 64, 512}, {"B4 C=128 64x64", 80, 4096, 128, 64}, {"B4 C=256 32x32", 80, 1024, 256, 32}};
     for (const Shp& s : shapes) {
         const int hidden = s.C / 2 > 16 ? s.C / 2 : 16;
-        const size_t nrec = (size_t)s.frames * s.nchunk * (s.C + 2), nel = (size_t)s.frames * s.P * s.C;
+        const size_t nrec = (size_t)s.frames * s.nchunk * (s.C + 2), nel = gate_only ? 1024 : (size_t)s.frames * s.P * s.C;
         std::vector<float> part(nrec), w1t((size_t)s.C * hidden), b1(hidden), w2t((size_t)hidden * s.C), b2(s.C);
         for (size_t r = 0; r < (size_t)s.frames * s.nchunk; ++r) {
             float* q = &part[r * (s.C + 2)];
@@ -53,6 +55,21 @@ int main(int argc, char** argv) {
         void *dy = to_dev(y.data(), nel * 2), *dres = to_dev(res.data(), nel * 2), *dout0, *dout1; float* dgate;
         CK(hipMalloc(&dout0, nel * 2)); CK(hipMalloc(&dout1, nel * 2)); CK(hipMalloc((void**)&dgate, (size_t)s.frames * s.C * 4));
         auto two = [&] { int rc = p_gate(dpart, dw1, db1, dw2, db2, dgate, s.frames, s.C, hidden, s.nchunk, st); if (!rc) rc = p_apply(0, dy, dgate, dres, dout0, s.frames, s.P, s.C, st); return rc; };
+        if (gate_only) {       // mv2_se_gate against the variant with its independent loads hoisted (same sums): gates bit for bit, us per launch
+            if (!p_gate2) { printf("no mv2x_se_gate_v2\n"); return 2; }
+            float* dgate2; CK(hipMalloc((void**)&dgate2, (size_t)s.frames * s.C * 4)); CK(hipMemset(dgate2, 0xff, (size_t)s.frames * s.C * 4));
+            auto g1 = [&] { return p_gate(dpart, dw1, db1, dw2, db2, dgate, s.frames, s.C, hidden, s.nchunk, st); };
+            auto g2 = [&] { return p_gate2(dpart, dw1, db1, dw2, db2, dgate2, s.frames, s.C, hidden, s.nchunk, st); };
+            int r1 = g1(), r2 = g2(); CK(hipStreamSynchronize(st));
+            std::vector<uint32_t> a((size_t)s.frames * s.C), b2v(a.size());
+            CK(hipMemcpy(a.data(), dgate, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b2v.data(), dgate2, a.size() * 4, hipMemcpyDeviceToHost));
+            size_t diff = 0; for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b2v[i];
+            printf("== gate only %-28s rc %d %d, differing gate words %zu of %zu:", s.name, r1, r2, diff, a.size());
+            for (int pass = 0; pass < 2; ++pass) printf("  se_gate %5.1f us -> hoisted loads %5.1f us |", time_us(g1, 50, st), time_us(g2, 50, st));
+            printf("\n");
+            hipFree(dgate2); hipFree(dpart); hipFree(dw1); hipFree(db1); hipFree(dw2); hipFree(db2); hipFree(dy); hipFree(dres); hipFree(dout0); hipFree(dout1); hipFree(dgate);
+            continue;
+        }
         int rc = two(); CK(hipStreamSynchronize(st));
         if (rc) { printf("%s: two-launch form rc=%d\n", s.name, rc); continue; }
         std::vector<uint16_t> o0(nel), o1(nel);
