@@ -89,3 +89,122 @@ extern "C" int mv2x_taylor_kv_head_major(int dtype, const void* kv_hm, float* st
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// EXPERIMENTS ONLY: the Taylor state on the matrix pipe (bf16 inputs).  Per (frame, head):
+//     State[f][e] = sum_n phi_f(k_n) * ve_e(n),   f in [0, 73), ve = [v_0 .. v_7, 1]
+// as D[32 feature rows][32 columns (9 used)] += A[32 x 16 tokens] * B[16 tokens x 32] with v_mfma_f32_32x32x16_bf16, three feature tiles.
+// Both operands need the TOKENS along k, i.e. 8 consecutive tokens of one component in 16 bytes, and the projection writes tokens as the
+// slow axis: a chunk of 1024 tokens is transposed into LDS once (kT[8][1024], vT[10][1024] bf16: row 8 = 1 for live tokens, row 9 = 0).
+// A lane builds its A fragment from two 16-byte reads: phi_f = (k_a * k_b) * scale with (a, b, scale) fixed per lane and tile - the
+// constant and the linear features read a row of ones for the missing factor, rows past 72 the row of zeros - so the code is branch-free.
+// SPLIT = 2: phi in two bf16 terms (hi + lo, two MFMAs): the state then carries ~16 significant bits of phi instead of 8 (v is bf16
+// already, exact).  Four waves take 256 tokens of a chunk each; the partial tiles meet through LDS in a fixed order.
+// reference: TaylorSeriesLinearAttn (third party, restated in oracle/thirdparty.py) via LinearAttention.forward magvit2_pytorch.py:421-430.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void taylor_kv_mfma_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads) {
+    constexpr int CH = 1024, ROWB = CH * 2;                      // tokens per chunk; bytes per transposed row
+    constexpr int ONES = 16 * ROWB, ZERO = 17 * ROWB;            // rows: 0..7 kT, 8..15 vT, 16 ones (live tokens), 17 zeros
+    __shared__ __attribute__((aligned(16))) char smem[18 * ROWB];                  // 36 KB; the cross-wave sum reuses it (3 x 12 KB)
+    const int f = blockIdx.y, h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 2 * heads * 8;
+    // per lane and tile: the two rows whose product is its feature, and the scale
+    int rowA[3], rowB[3]; float sc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int ft = 32 * m + l31;
+        if (ft == 0) { rowA[m] = ONES; rowB[m] = ONES; sc[m] = 1.f; }
+        else if (ft <= 8) { rowA[m] = (ft - 1) * ROWB; rowB[m] = ONES; sc[m] = 1.f; }
+        else if (ft < 73) { rowA[m] = ((ft - 9) >> 3) * ROWB; rowB[m] = ((ft - 9) & 7) * ROWB; sc[m] = 0.70710678118654752440f; }
+        else { rowA[m] = ZERO; rowB[m] = ZERO; sc[m] = 0.f; }
+    }
+    const int rowV = (l31 < 8 ? 8 + l31 : (l31 == 8 ? 16 : 17)) * ROWB;            // B operand: column e = l31 (v_e, the ones, zeros)
+    f32x16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int c0 = 0; c0 < n; c0 += CH) {
+        if (c0) __syncthreads();                                 // everybody has read the previous chunk
+        // ---- transpose the chunk: thread -> tokens tid, tid + 256, ...
+#pragma unroll
+        for (int q = 0; q < CH / 256; ++q) {
+            const int tt = tid + 256 * q, t = c0 + tt;
+            const bool live = t < n;
+            const int64_t row = ((int64_t)f * n + (live ? t : n - 1)) * ld;
+            i32x4 kr = *(const i32x4*)((const char*)kv + (row + h * 8) * 2);
+            i32x4 vr = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * 2);
+            if (!live) { kr = i32x4{0, 0, 0, 0}; vr = i32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(unsigned short*)(smem + (2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)kr[j] & 0xffffu);
+                *(unsigned short*)(smem + (2 * j + 1) * ROWB + tt * 2) = (unsigned short)((unsigned)kr[j] >> 16);
+                *(unsigned short*)(smem + (8 + 2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)vr[j] & 0xffffu);
+                *(unsigned short*)(smem + (9 + 2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)vr[j] >> 16);
+            }
+            *(unsigned short*)(smem + ONES + tt * 2) = live ? (unsigned short)0x3f80 : (unsigned short)0;
+            *(unsigned short*)(smem + ZERO + tt * 2) = 0;
+        }
+        __syncthreads();
+        // ---- wave w: tokens [256 w, 256 w + 256) of the chunk, 16 tokens per MFMA step
+        for (int s = 0; s < 16; ++s) {
+            const int tb0 = 256 * wave + 16 * s;
+            if (c0 + tb0 >= n) break;                            // wave-uniform: nothing live from here on
+            const int tbo = (tb0 + 8 * hi) * 2;                  // byte offset of this lane's 8 tokens inside a row
+            const i32x4 bfrag = *(const i32x4*)(smem + rowV + tbo);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float ka[8], kb[8], p[8];
+                Chunk<BF16>::unpack(*(const i32x4*)(smem + rowA[m] + tbo), ka);
+                Chunk<BF16>::unpack(*(const i32x4*)(smem + rowB[m] + tbo), kb);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = (ka[u] * kb[u]) * sc[m];
+                const i32x4 ahi = Chunk<BF16>::pack(p);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ahi), __builtin_bit_cast(bf16x8, bfrag), acc[m], 0, 0, 0);
+                if constexpr (SPLIT == 2) {
+                    float ph[8];
+                    Chunk<BF16>::unpack(ahi, ph);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p[u] -= ph[u];
+                    const i32x4 alo = Chunk<BF16>::pack(p);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, alo), __builtin_bit_cast(bf16x8, bfrag), acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- cross-wave sum (waves 1..3 -> LDS, wave 0 adds in wave order) and the state rows
+    __syncthreads();
+    float* red = (float*)smem;                                   // [wave - 1][tile][r][lane]
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave - 1) * 3 + m) * 16 + r) * 64 + lane] = acc[m][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = state + ((int64_t)f * heads + h) * TAY_S;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[m][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[((w * 3 + m) * 16 + r) * 64 + lane];
+                const int ft = 32 * m + 8 * (r >> 2) + 4 * hi + (r & 3);      // D row of this register; column = l31
+                if (ft < TAY_F && l31 < 9) dst[ft * 9 + l31] = v;
+            }
+    }
+}
+
+extern "C" int mv2x_taylor_kv_mfma(const void* kv, float* state, int frames, int n, int heads, int split, void* stream) {
+    if (!kv || !state || frames <= 0 || n <= 0 || heads <= 0 || (split != 1 && split != 2)) return MV2_EINVAL;
+    dim3 grid((unsigned)heads, (unsigned)frames);
+    hipStream_t st = (hipStream_t)stream;
+    if (split == 1) hipLaunchKernelGGL((taylor_kv_mfma_kernel<1>), grid, dim3(256), 0, st, kv, state, n, heads);
+    else hipLaunchKernelGGL((taylor_kv_mfma_kernel<2>), grid, dim3(256), 0, st, kv, state, n, heads);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}

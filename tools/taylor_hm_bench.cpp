@@ -3,6 +3,7 @@
 // Build: hipcc -O2 -std=c++17 tools/taylor_hm_bench.cpp -o tools/taylor_hm_bench -ldl
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +11,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 typedef int (*kv_fn)(int, const void*, float*, int, int, int, int, void*);
 typedef int (*kvhm_fn)(int, const void*, float*, int, int, int, void*);
+typedef int (*kvmfma_fn)(const void*, float*, int, int, int, int, void*);
 static uint32_t rng_state = 7u;
 static inline float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
@@ -27,10 +29,13 @@ int main(int argc, char** argv) {
     if (!h) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     kv_fn p_kv = (kv_fn)dlsym(h, "mv2_taylor_kv"); kvhm_fn p_hm = (kvhm_fn)dlsym(h, "mv2x_taylor_kv_head_major");
     if (!p_kv || !p_hm) { printf("missing symbols (experiments library?)\n"); return 2; }
+    kvmfma_fn p_mf = (kvmfma_fn)dlsym(h, "mv2x_taylor_kv_mfma");
+    const bool mfma_only = argc > 2 && !strcmp(argv[2], "mfma");
     hipStream_t st; CK(hipStreamCreate(&st));
     const int heads = 16;
     struct Shp { const char* name; int frames, n; };
-    const Shp shapes[] = {{"configs[1]: 20 frames x 1024 tokens", 20, 1024}, {"batch 4: 80 frames x 1024 tokens", 80, 1024}, {"ragged: 7 frames x 933 tokens", 7, 933}};
+    const Shp shapes[] = {{"configs[1]: 20 frames x 1024 tokens", 20, 1024}, {"batch 4: 80 frames x 1024 tokens", 80, 1024}, {"ragged: 7 frames x 933 tokens", 7, 933},
+                          {"tiny: 3 frames x 5 tokens", 3, 5}, {"two chunks + tail: 3 frames x 2100 tokens", 3, 2100}};
     for (const Shp& s : shapes) {
         const int ld = 2 * heads * 8;
         std::vector<uint16_t> rows((size_t)s.frames * s.n * ld), hm(rows.size());
@@ -45,6 +50,27 @@ int main(int argc, char** argv) {
         CK(hipMemset(s0, 0, sb)); CK(hipMemset(s1, 0xff, sb));
         auto a = [&] { return p_kv(0, drows, s0, s.frames, s.n, heads, 1, st); };
         auto b = [&] { return p_hm(0, dhm, s1, s.frames, s.n, heads, st); };
+        if (mfma_only) {       // the state on the matrix pipe (one / two bf16 terms of phi) against the VALU kernel: max |difference| relative to max |state|
+            if (!p_mf) { printf("no mv2x_taylor_kv_mfma\n"); return 2; }
+            int r0 = a(); CK(hipStreamSynchronize(st));
+            std::vector<float> ref(sb / 4), got(sb / 4);
+            CK(hipMemcpy(ref.data(), s0, sb, hipMemcpyDeviceToHost));
+            double amax = 0; for (float v : ref) amax = fabs(v) > amax ? fabs(v) : amax;
+            printf("== %-42s (VALU kernel rc %d, max |state| %.3g)\n", s.name, r0, amax);
+            for (int split = 1; split <= 2; ++split) {
+                CK(hipMemset(s1, 0xff, sb));
+                auto m = [&] { return p_mf(drows, s1, s.frames, s.n, heads, split, st); };
+                int rm = m(); CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(got.data(), s1, sb, hipMemcpyDeviceToHost));
+                double dmax = 0, dsum = 0; size_t nan = 0;
+                for (size_t i = 0; i < ref.size(); ++i) { const double d = fabs((double)got[i] - ref[i]); if (!(d == d)) ++nan; else { dmax = d > dmax ? d : dmax; dsum += d; } }
+                printf("   %d bf16 term(s) of phi: rc %d, max |d| %.3g (%.2e of max |state|), mean |d| %.3g, nan %zu |", split, rm, dmax, dmax / (amax + 1e-30), dsum / ref.size(), nan);
+                for (int pass = 0; pass < 2; ++pass) printf(" VALU %5.1f us  MFMA %5.1f us |", time_us(a, 30, st), time_us(m, 30, st));
+                printf("\n");
+            }
+            hipFree(drows); hipFree(dhm); hipFree(s0); hipFree(s1);
+            continue;
+        }
         int ra = a(), rb = b(); CK(hipStreamSynchronize(st));
         std::vector<uint32_t> h0(sb / 4), h1(sb / 4);
         CK(hipMemcpy(h0.data(), s0, sb, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), s1, sb, hipMemcpyDeviceToHost));
