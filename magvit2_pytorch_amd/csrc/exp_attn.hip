@@ -128,50 +128,66 @@ __global__ __launch_bounds__(256) void taylor_kv_mfma_kernel(const void* __restr
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     for (int c0 = 0; c0 < n; c0 += CH) {
         if (c0) __syncthreads();                                 // everybody has read the previous chunk
-        // ---- transpose the chunk: thread -> tokens tid, tid + 256, ...
+        // ---- transpose the chunk: thread -> token PAIRS tid, tid + 256 (tokens 2 p, 2 p + 1): one 4-byte LDS write per row and pair
 #pragma unroll
-        for (int q = 0; q < CH / 256; ++q) {
-            const int tt = tid + 256 * q, t = c0 + tt;
-            const bool live = t < n;
-            const int64_t row = ((int64_t)f * n + (live ? t : n - 1)) * ld;
-            i32x4 kr = *(const i32x4*)((const char*)kv + (row + h * 8) * 2);
-            i32x4 vr = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * 2);
-            if (!live) { kr = i32x4{0, 0, 0, 0}; vr = i32x4{0, 0, 0, 0}; }
+        for (int q = 0; q < CH / 512; ++q) {
+            const int pp = tid + 256 * q, t0 = c0 + 2 * pp;
+            i32x4 kr[2], vr[2];
+            unsigned one[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bool live = t0 + x < n;
+                const int64_t row = ((int64_t)f * n + (live ? t0 + x : n - 1)) * ld;
+                kr[x] = *(const i32x4*)((const char*)kv + (row + h * 8) * 2);
+                vr[x] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * 2);
+                if (!live) { kr[x] = i32x4{0, 0, 0, 0}; vr[x] = i32x4{0, 0, 0, 0}; }
+                one[x] = live ? 0x3f80u : 0u;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                *(unsigned short*)(smem + (2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)kr[j] & 0xffffu);
-                *(unsigned short*)(smem + (2 * j + 1) * ROWB + tt * 2) = (unsigned short)((unsigned)kr[j] >> 16);
-                *(unsigned short*)(smem + (8 + 2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)vr[j] & 0xffffu);
-                *(unsigned short*)(smem + (9 + 2 * j) * ROWB + tt * 2) = (unsigned short)((unsigned)vr[j] >> 16);
+                const unsigned ka = (unsigned)kr[0][j], kb = (unsigned)kr[1][j], va = (unsigned)vr[0][j], vb = (unsigned)vr[1][j];
+                *(unsigned*)(smem + (2 * j) * ROWB + pp * 4) = (ka & 0xffffu) | (kb << 16);
+                *(unsigned*)(smem + (2 * j + 1) * ROWB + pp * 4) = (ka >> 16) | (kb & 0xffff0000u);
+                *(unsigned*)(smem + (8 + 2 * j) * ROWB + pp * 4) = (va & 0xffffu) | (vb << 16);
+                *(unsigned*)(smem + (9 + 2 * j) * ROWB + pp * 4) = (va >> 16) | (vb & 0xffff0000u);
             }
-            *(unsigned short*)(smem + ONES + tt * 2) = live ? (unsigned short)0x3f80 : (unsigned short)0;
-            *(unsigned short*)(smem + ZERO + tt * 2) = 0;
+            *(unsigned*)(smem + ONES + pp * 4) = one[0] | (one[1] << 16);
+            *(unsigned*)(smem + ZERO + pp * 4) = 0u;
         }
         __syncthreads();
-        // ---- wave w: tokens [256 w, 256 w + 256) of the chunk, 16 tokens per MFMA step
-        for (int s = 0; s < 16; ++s) {
+        // ---- wave w: tokens [256 w, 256 w + 256) of the chunk, 16 tokens per MFMA step, two steps per trip: the fourteen 16-byte fragment
+        // reads of a trip are issued before its math (one LDS latency per trip instead of one per tile and step)
+        for (int s = 0; s < 16; s += 2) {
             const int tb0 = 256 * wave + 16 * s;
-            if (c0 + tb0 >= n) break;                            // wave-uniform: nothing live from here on
-            const int tbo = (tb0 + 8 * hi) * 2;                  // byte offset of this lane's 8 tokens inside a row
-            const i32x4 bfrag = *(const i32x4*)(smem + rowV + tbo);
+            if (c0 + tb0 >= n) break;                            // wave-uniform: nothing live from here on (a half-dead trip multiplies zeros)
+            i32x4 bfr[2], ar[2][3], br[2][3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float ka[8], kb[8], p[8];
-                Chunk<BF16>::unpack(*(const i32x4*)(smem + rowA[m] + tbo), ka);
-                Chunk<BF16>::unpack(*(const i32x4*)(smem + rowB[m] + tbo), kb);
+            for (int x = 0; x < 2; ++x) {
+                const int tbo = (tb0 + 16 * x + 8 * hi) * 2;     // byte offset of this lane's 8 tokens inside a row
+                bfr[x] = *(const i32x4*)(smem + rowV + tbo);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = (ka[u] * kb[u]) * sc[m];
-                const i32x4 ahi = Chunk<BF16>::pack(p);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ahi), __builtin_bit_cast(bf16x8, bfrag), acc[m], 0, 0, 0);
-                if constexpr (SPLIT == 2) {
-                    float ph[8];
-                    Chunk<BF16>::unpack(ahi, ph);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) p[u] -= ph[u];
-                    const i32x4 alo = Chunk<BF16>::pack(p);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, alo), __builtin_bit_cast(bf16x8, bfrag), acc[m], 0, 0, 0);
-                }
+                for (int m = 0; m < 3; ++m) { ar[x][m] = *(const i32x4*)(smem + rowA[m] + tbo); br[x][m] = *(const i32x4*)(smem + rowB[m] + tbo); }
             }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    float ka[8], kb[8], p[8];
+                    Chunk<BF16>::unpack(ar[x][m], ka);
+                    Chunk<BF16>::unpack(br[x][m], kb);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p[u] = (ka[u] * kb[u]) * sc[m];
+                    const i32x4 ahi = Chunk<BF16>::pack(p);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ahi), __builtin_bit_cast(bf16x8, bfr[x]), acc[m], 0, 0, 0);
+                    if constexpr (SPLIT == 2) {
+                        float ph[8];
+                        Chunk<BF16>::unpack(ahi, ph);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) p[u] -= ph[u];
+                        const i32x4 alo = Chunk<BF16>::pack(p);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, alo), __builtin_bit_cast(bf16x8, bfr[x]), acc[m], 0, 0, 0);
+                    }
+                }
         }
     }
     // ---- cross-wave sum (waves 1..3 -> LDS, wave 0 adds in wave order) and the state rows
@@ -205,6 +221,92 @@ extern "C" int mv2x_taylor_kv_mfma(const void* kv, float* state, int frames, int
     hipStream_t st = (hipStream_t)stream;
     if (split == 1) hipLaunchKernelGGL((taylor_kv_mfma_kernel<1>), grid, dim3(256), 0, st, kv, state, n, heads);
     else hipLaunchKernelGGL((taylor_kv_mfma_kernel<2>), grid, dim3(256), 0, st, kv, state, n, heads);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// EXPERIMENTS ONLY: taylor_kv_frame_kernel with the frame's tokens cut into nchunk ranges (grid z): nchunk partial states per (frame,
+// head) in taylor_kv_kernel's layout.  320 workgroups on 256 CUs take two rounds (a lone workgroup needs 13.5 us, the launch 22.3);
+// 640 / 1280 half- or quarter-length workgroups are all resident at once.  The partial states would be summed where mv2_taylor_apply
+// stages the state (a few KB per block), not by a reduce launch.
+template <typename E>
+__global__ __launch_bounds__(256) void taylor_kv_frame_split_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads, int nchunk) {
+    __shared__ float red[4][8][92];
+    const int f = blockIdx.y, h = blockIdx.x, z = blockIdx.z;
+    const int per = (n + nchunk - 1) / nchunk, tbeg = z * per, tend = min(n, tbeg + per);      // this workgroup's token range
+    const int tid = threadIdx.x, i = tid & 7, tg = tid >> 3, wave = tid >> 6;
+    const int ld = 2 * heads * 8;
+    constexpr int NC = 8 / E::kVec, U = 4;
+    float a2[8][9], a1[9], a0[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { a1[e] = 0.f; a0[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
+    const float r2 = 0.70710678118654752440f;
+    for (int t0 = tbeg + tg; t0 < tend; t0 += 32 * U) {
+        i32x4 kr[U][NC], vr[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + 32 * u, tend - 1);                  // clamped: the tail trip re-reads a valid row and is masked below
+            const int64_t row = ((int64_t)f * n + t) * ld;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                kr[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
+                vr[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float k[8], v[9];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { Chunk<E>::unpack(kr[u][c], k + c * E::kVec); Chunk<E>::unpack(vr[u][c], v + c * E::kVec); }
+            const bool live = t0 + 32 * u < tend;
+            v[8] = live ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = live ? v[e] : 0.f;
+            float ki = k[0];
+#pragma unroll
+            for (int jj = 1; jj < 8; ++jj) ki = (i == jj) ? k[jj] : ki;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { a0[e] += v[e]; a1[e] += ki * v[e]; }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float ph = (ki * k[jj]) * r2;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) a2[jj][e] += ph * v[e];
+            }
+        }
+    }
+    // the eight token groups of a wave: lanes with equal i
+    auto wred = [&](float x) { x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); return x; };
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { a0[e] = wred(a0[e]); a1[e] = wred(a1[e]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a2[jj][e] = wred(a2[jj][e]); }
+    if ((tid & 63) < 8) {
+        float* r = red[wave][i];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { r[e] = a0[e]; r[9 + e] = a1[e];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) r[18 + jj * 9 + e] = a2[jj][e]; }
+    }
+    __syncthreads();
+    float* dst = state + (((int64_t)f * nchunk + z) * heads + h) * TAY_S;      // the partial-state layout of taylor_kv_kernel
+    for (int x = tid; x < 8 * 90; x += 256) {
+        const int ii = x / 90, r = x - ii * 90;
+        const float s = ((red[0][ii][r] + red[1][ii][r]) + red[2][ii][r]) + red[3][ii][r];
+        if (r < 9) { if (ii == 0) dst[r] = s; }                                   // row 0: sum of [v, 1] (every i holds a copy)
+        else if (r < 18) dst[(1 + ii) * 9 + (r - 9)] = s;                          // row 1 + i
+        else dst[(9 + 8 * ii + (r - 18) / 9) * 9 + (r - 18) % 9] = s;             // row 9 + 8 i + j
+    }
+}
+
+
+extern "C" int mv2x_taylor_kv_split(const void* kv, float* part, int frames, int n, int heads, int nchunk, void* stream) {
+    if (!kv || !part || frames <= 0 || n <= 0 || heads <= 0 || nchunk <= 0 || nchunk > 16) return MV2_EINVAL;
+    dim3 grid((unsigned)heads, (unsigned)frames, (unsigned)nchunk);
+    hipLaunchKernelGGL((taylor_kv_frame_split_kernel<BF16>), grid, dim3(256), 0, (hipStream_t)stream, kv, part, n, heads, nchunk);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }

@@ -31,6 +31,9 @@ int main(int argc, char** argv) {
     if (!p_kv || !p_hm) { printf("missing symbols (experiments library?)\n"); return 2; }
     kvmfma_fn p_mf = (kvmfma_fn)dlsym(h, "mv2x_taylor_kv_mfma");
     const bool mfma_only = argc > 2 && !strcmp(argv[2], "mfma");
+    typedef int (*kvsplit_fn)(const void*, float*, int, int, int, int, void*);
+    kvsplit_fn p_sp = (kvsplit_fn)dlsym(h, "mv2x_taylor_kv_split");
+    const bool split_only = argc > 2 && !strcmp(argv[2], "split");
     hipStream_t st; CK(hipStreamCreate(&st));
     const int heads = 16;
     struct Shp { const char* name; int frames, n; };
@@ -50,6 +53,31 @@ int main(int argc, char** argv) {
         CK(hipMemset(s0, 0, sb)); CK(hipMemset(s1, 0xff, sb));
         auto a = [&] { return p_kv(0, drows, s0, s.frames, s.n, heads, 1, st); };
         auto b = [&] { return p_hm(0, dhm, s1, s.frames, s.n, heads, st); };
+        if (split_only) {      // the VALU kernel on nchunk token ranges per (frame, head): partial states summed on the host against the whole-frame state
+            if (!p_sp) { printf("no mv2x_taylor_kv_split\n"); return 2; }
+            int r0 = a(); CK(hipStreamSynchronize(st));
+            std::vector<float> ref(sb / 4);
+            CK(hipMemcpy(ref.data(), s0, sb, hipMemcpyDeviceToHost));
+            double amax = 0; for (float v : ref) amax = fabs(v) > amax ? fabs(v) : amax;
+            printf("== %-42s whole frame %5.1f us (rc %d) |", s.name, time_us(a, 30, st), r0);
+            for (int nc : {2, 4, 8}) {
+                float* dp; CK(hipMalloc((void**)&dp, sb * nc)); CK(hipMemset(dp, 0xff, sb * nc));
+                auto m = [&] { return p_sp(drows, dp, s.frames, s.n, heads, nc, st); };
+                int rm = m(); CK(hipStreamSynchronize(st));
+                std::vector<float> got((size_t)nc * sb / 4);
+                CK(hipMemcpy(got.data(), dp, sb * nc, hipMemcpyDeviceToHost));
+                double dmax = 0; const size_t per_fh = 73 * 9;
+                for (int ff = 0; ff < s.frames; ++ff) for (int hh = 0; hh < heads; ++hh) for (size_t e = 0; e < per_fh; ++e) {
+                    double sum = 0; for (int z = 0; z < nc; ++z) sum += got[(((size_t)ff * nc + z) * heads + hh) * per_fh + e];
+                    const double d = fabs(sum - ref[((size_t)ff * heads + hh) * per_fh + e]); if (!(d <= dmax)) dmax = d;
+                }
+                printf(" %d ranges: rc %d %5.1f us (sum differs by %.1e of max) |", nc, rm, time_us(m, 30, st), dmax / (amax + 1e-30));
+                hipFree(dp);
+            }
+            printf("\n");
+            hipFree(drows); hipFree(dhm); hipFree(s0); hipFree(s1);
+            continue;
+        }
         if (mfma_only) {       // the state on the matrix pipe (one / two bf16 terms of phi) against the VALU kernel: max |difference| relative to max |state|
             if (!p_mf) { printf("no mv2x_taylor_kv_mfma\n"); return 2; }
             int r0 = a(); CK(hipStreamSynchronize(st));
