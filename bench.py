@@ -12,6 +12,7 @@ Metric (BASELINE.json): video frames/sec, encode+decode, 128^2 x 17 frames, bf16
 ``forward(video, return_codes=True, return_recon=True)`` over this rank's batch of synthetic clips.
   --config 1 (default at N = 1): BASELINE configs[1], (1,3,17,128,128) per GPU
   --config 2 (default at N > 1): BASELINE configs[2], global batch 32 on 8 GPUs = (4,3,17,128,128) per GPU
+  --config 3                   : BASELINE configs[3], (4,3,33,256,256) per GPU: space attention over 1024 + 4 keys (the MFMA attention kernel)
   --config 4                   : BASELINE configs[4], FSQ [8,5,5,5], 65 frames, (2,3,65,128,128) per GPU, tokenize() only
 README layer spec, weights random-init with the reference's init families (seed 0), SqueezeExcite output layer
 re-randomised so residual branches are live.  Inputs are resident in HBM before the timed region.  Clips are independent
@@ -26,8 +27,13 @@ Extra objects on the JSON line:
                    durations, each measured live with HIP events on the launch stream; frac_executed = the same with the flops the
                    kernel executes (it skips the time taps in the causal zero padding, which the reference multiplies).  traffic:
                    HBM-side bytes per launch from the committed rocprofv3 PMC passes (`traffic_source` names the file; null when none applies).
+                   `encode_path`, `all_conv_launches`, `gemm_family_non_conv3` come from the same event table, in which every launch is
+                   issued 5x back to back (L2 / MALL-warm repeats): relative figures, labelled `warm_repeat_events`.
   batch4         — (N = 1, configs[1]) the per-GPU shape of configs[2], 4 clips per step, timed in the same process: ms/step,
-                   frames/s and the conv3 fraction at that shape.
+                   frames/s and the conv3 fraction at that shape.  This is the same-shape base of the N > 1 lines.
+  configs3       — (N = 1, configs[1]) BASELINE configs[3] timed in the same process (>= 5 steps): ms/step, frames/s, conv3 fraction and the
+                   roofline of the MFMA attention kernel at 1024 + 4 keys (QK^T + PV flops / event time / 2.5 PF).
+  configs4_fsq   — (N = 1, configs[1]) BASELINE configs[4]'s per-GPU shape, tokenize() only.
   exact_fp32_mode— (N = 1, configs[1]) throughput and id mismatch of the bit-exact mode (fp32 storage + fp32 MFMA).
   cpu_baseline   — kind "reference": the reference's own VideoTokenizer.forward (build-time copy oracle/_ref, loaded by oracle/ref_loader.py)
                    timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only); kind "port"
@@ -35,8 +41,13 @@ Extra objects on the JSON line:
                    timed runs, chosen by the printed thread sweep (small sample, ascending, cut at 3x the best) up to `cores_available`; plus its
                    bf16-autocast drift (one draw of the tolerance yardstick; the six-seed yardstick of the tests comes from the
                    real reference, tests/golden/bf16_yardstick.json).
-  rccl_ranks / per_rank_ms_per_step — (N > 1) torch.distributed world size and every rank's own ms/step (all_gather over RCCL).
-  roofline.encode_path — MFMA and HBM fractions of the encoder launches alone (the path north_star names), same event table.
+  rccl_ranks / per_rank_ms_per_step / weak_scaling_base — (N > 1) torch.distributed world size, every rank's own ms/step (all_gather over
+                   RCCL) and the same-shape single-GPU base the line must be compared with: N = 1 defaults to configs[1] (1 clip per GPU),
+                   N > 1 to configs[2] (4 clips per GPU), so value(N) / value(1) of the default lines is NOT a scaling figure.
+  scaling_curve  — (N = 1) says that no curve was measured in this run and which object holds the same-shape base.
+
+--dry-run-backend emulation: the whole control path (respawn, rendezvous, barriers, gather_codes, JSON assembly) on CPU with the
+kernel-semantics emulation injected and a tiny spec, gloo instead of RCCL.  It exists for tests/test_host_logic.py: its numbers mean nothing.
 """
 from __future__ import annotations
 
@@ -52,6 +63,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 _T0 = time.perf_counter()
+PEAK_BF16, PEAK_F32 = 2500.0, 157.3          # TFLOP/s dense (MI355X_MICROARCH.md)
+GEMM_WHATS = ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_in', 'mv2_conv_out', 'mv2_conv3', 'mv2_pw_se', 'mv2_ff')
 
 
 def log(msg):
@@ -59,12 +72,12 @@ def log(msg):
         print(f'[bench +{time.perf_counter() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 4], help='BASELINE.json configs index (0 = 1 at N = 1, 2 at N > 1)')
+    ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4], help='BASELINE.json configs index (0 = 1 at N = 1, 2 at N > 1)')
     ap.add_argument('--batch-per-gpu', type=int, default=0, help='override the clips per GPU of the chosen config')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-graph', action='store_true')
@@ -72,19 +85,23 @@ def parse():
     ap.add_argument('--no-exact', action='store_true', help='skip the exact-fp32-mode leg')
     ap.add_argument('--no-soak', action='store_true')
     ap.add_argument('--no-batch4', action='store_true', help='skip the configs[2] per-GPU-shape leg of the N = 1 line')
+    ap.add_argument('--no-configs34', action='store_true', help='skip the configs[3] / configs[4] legs of the N = 1 line')
     ap.add_argument('--breakdown', default='', help='write the per-launch timing table to this json file')
-    return ap.parse_args()
+    ap.add_argument('--dry-run-backend', default='', choices=['', 'emulation'],
+                    help='emulation: CPU kernel emulation + gloo + a tiny spec; exercises the control path only (tests)')
+    return ap.parse_args(argv)
 
 
 def respawn_if_needed(args):
     """--gpus N without a torchrun environment: launch N ranks of this script (never time 1 GPU and call it N)."""
     if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
         return
-    import torch
-    n = torch.cuda.device_count()
-    if n < args.gpus:
-        print(f'bench.py: --gpus {args.gpus} but only {n} device(s) visible', file=sys.stderr)
-        sys.exit(3)
+    if not args.dry_run_backend:
+        import torch
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            print(f'bench.py: --gpus {args.gpus} but only {n} device(s) visible', file=sys.stderr)
+            sys.exit(3)
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -93,13 +110,55 @@ def respawn_if_needed(args):
 
 
 def kernel_source_hash():
-    """sha256 over the conv3 kernel sources: what profiles/r03_traffic.json is stamped with (tools/pmc_aggregate.py)"""
+    """sha256 over the conv3 kernel sources: what profiles/rNN_traffic.json is stamped with (tools/pmc_aggregate.py)"""
     import hashlib
     h = hashlib.sha256()
     for fn in ('conv3.hip', 'conv3p.hip', 'conv3p.h', 'conv_common.h', 'common.h'):
         with open(os.path.join(ROOT, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def workload(cfg_id, tiny=False):
+    """-> (ctor kwargs, clips per GPU, frames, image size, tokenize_only, description) of BASELINE.json configs[cfg_id]"""
+    from magvit2_pytorch_amd import README_LAYERS
+    size = 256 if cfg_id == 3 else 128
+    kw = dict(image_size=size, init_dim=64, max_dim=512, layers=README_LAYERS)
+    if cfg_id == 4:
+        kw.update(use_fsq=True, fsq_levels=[8, 5, 5, 5])
+        B, T, tokenize_only = 2, 65, True
+        what = 'BASELINE configs[4]: FSQ [8,5,5,5], tokenize() only'
+    else:
+        kw.update(codebook_size=1024)
+        B, T, tokenize_only = {1: 1, 2: 4, 3: 4}[cfg_id], (33 if cfg_id == 3 else 17), False
+        what = f'BASELINE configs[{cfg_id}]: LFQ K=1024, forward(return_codes, return_recon)'
+    if tiny:        # control-path dry run: same structure, toy sizes (the emulation is a CPU program)
+        size = 32
+        kw.update(image_size=32, init_dim=8, max_dim=32)
+        if cfg_id != 4:
+            kw.update(codebook_size=256)
+        B, T = min(B, 2), 5
+        what += ' [DRY RUN: tiny spec on the CPU emulation, numbers are meaningless]'
+    return kw, B, T, size, tokenize_only, what
+
+
+def make_tokenizer(kw, dev, dtype, graph, emulation=False):
+    import torch
+    from magvit2_pytorch_amd import VideoTokenizer
+    from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=0, randomize_se=True)
+    tok = VideoTokenizer(**kw, seed=0)
+    tok.load_state_dict(sd)
+    if emulation:
+        from oracle.ndhwc_ops import CpuOps          # dry run only: never on a timed path
+        tok._set_backend(CpuOps())
+        tok.compute_dtype = torch.float32
+    else:
+        tok = tok.to(dev)
+        tok.compute_dtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    tok.use_hip_graph = graph
+    return tok, cfg, sd
 
 
 def per_launch_profile(tok, video, ops, tokenize_only=False):
@@ -135,41 +194,60 @@ def per_launch_profile(tok, video, ops, tokenize_only=False):
     return rows
 
 
+def conv3_summary(rows, peak):
+    k3 = [r for r in rows if r['what'] == 'mv2_conv3']      # incl. the fused '.k3+k1' launches (their FLOPs include the 1x1x1)
+    ms = sum(r['ms'] for r in k3)
+    a = sum(r['flops'] for r in k3) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    ax = sum(r['flops_exec'] for r in k3) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return dict(achieved=round(a, 2), frac=round(a / peak, 4), achieved_executed=round(ax, 2), frac_executed=round(ax / peak, 4),
+                avg_launch_ms=round(ms / max(len(k3), 1), 5), launches=len(k3), flops_per_launch=sum(r['flops'] for r in k3) / max(len(k3), 1),
+                ms_per_step=round(ms, 4))
+
+
+def family_summary(rows, whats, peak, exclude=()):
+    sel = [r for r in rows if r['what'] in whats and r['what'] not in exclude]
+    ms, fl = sum(r['ms'] for r in sel), sum(r['flops'] for r in sel)
+    a = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return dict(launches=len(sel), flops_per_step=fl, ms_per_step=round(ms, 4), achieved=round(a, 2), frac=round(a / peak, 4),
+                timing='warm_repeat_events')
+
+
+def timed(fn, n, sync):
+    sync()
+    t = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t) / n, out
+
+
 def main():
     args = parse()
     respawn_if_needed(args)
     import torch
-    from magvit2_pytorch_amd import README_LAYERS, VideoTokenizer
     from magvit2_pytorch_amd import distributed as D
-    from magvit2_pytorch_amd.spec import init_state_dict, make_cfg
 
-    rank, world, local = D.init_from_env('nccl' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None)
+    emu = args.dry_run_backend == 'emulation'
+    multi = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    rank, world, local = D.init_from_env(('gloo' if emu else 'nccl') if multi else None)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device: the product path has no CPU fallback'
-    assert torch.cuda.device_count() > local, f'rank {rank}: device {local} not visible'
-    dev = torch.device(f'cuda:{local}')
-    torch.cuda.set_device(dev)
+    if emu:
+        dev = torch.device('cpu')
+        torch.set_num_threads(2)
+        sync = lambda: None
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a HIP device: the product path has no CPU fallback'
+        assert torch.cuda.device_count() > local, f'rank {rank}: device {local} not visible'
+        dev = torch.device(f'cuda:{local}')
+        torch.cuda.set_device(dev)
+        sync = lambda: torch.cuda.synchronize(dev)
 
     cfg_id = args.config or (1 if world == 1 else 2)
-    kw = dict(image_size=128, init_dim=64, max_dim=512, layers=README_LAYERS)
-    if cfg_id == 4:
-        kw.update(use_fsq=True, fsq_levels=[8, 5, 5, 5])
-        B, T, tokenize_only = 2, 65, True
-        what = 'BASELINE configs[4]: FSQ [8,5,5,5], tokenize() only'
-    else:
-        kw.update(codebook_size=1024)
-        B, T, tokenize_only = (1 if cfg_id == 1 else 4), 17, False
-        what = f'BASELINE configs[{cfg_id}]: LFQ K=1024, forward(return_codes, return_recon)'
+    kw, B, T, size, tokenize_only, what = workload(cfg_id, tiny=emu)
     if args.batch_per_gpu > 0:
         B = args.batch_per_gpu
-    cfg = make_cfg(**kw)
-    sd = init_state_dict(cfg, seed=0, randomize_se=True)
-    tok = VideoTokenizer(**kw, seed=0)
-    tok.load_state_dict(sd)
-    tok = tok.to(dev)
-    tok.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    tok.use_hip_graph = not args.no_graph
-    video = torch.randn(B, 3, T, 128, 128, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    tok, cfg, sd = make_tokenizer(kw, dev, args.dtype, not args.no_graph, emulation=emu)
+    video = torch.randn(B, 3, T, size, size, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     log(f'model + input ready on {dev} ({args.dtype}, config {cfg_id}, B={B}, T={T}, world={world})')
 
     def step():
@@ -177,33 +255,34 @@ def main():
             return tok.tokenize(video), None
         return tok(video, return_codes=True, return_recon=True)
 
-    warm = max(args.warmup, 3)                      # >= 3: eager run, graph capture, first replay
+    warm = max(args.warmup, 3) if not emu else 1   # >= 3: eager run, graph capture, first replay
     for _ in range(warm):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     soak_steps = 0
-    if not args.no_soak:                            # untimed, counted and reported: >= 1 s at full load
+    if not args.no_soak and not emu:                # untimed, counted and reported: >= 1 s at full load
         t_s = time.perf_counter()
         while time.perf_counter() - t_s < 1.0:
             for _ in range(10):
                 step()
             soak_steps += 10
-            torch.cuda.synchronize(dev)
+            sync()
     log(f'warm-up done ({warm} steps + {soak_steps} soak steps)')
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         codes, recon = step()
-    torch.cuda.synchronize(dev)
+    sync()
+    el_own = time.perf_counter() - t0              # this rank's K steps, before it waits for the others
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     rank_ms, rccl_ranks = None, None
     if world > 1:
         # evidence for the scaling record: every rank's own time (all_gather over RCCL) next to the max the value is computed from
-        mine = torch.tensor([el], dtype=torch.float64, device=dev)
+        mine = torch.tensor([el_own], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allt, mine)
         rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in allt]
@@ -224,215 +303,286 @@ def main():
     value = frames_total / el
     log(f'timed region: {el / args.steps * 1e3:.3f} ms/step over {args.steps} steps ({el:.2f} s) -> {value:.1f} frames/s')
 
-    # ---- roofline of the dominant kernel (rank 0)
-    ops = tok._backend()
-    rows = per_launch_profile(tok, video, ops, tokenize_only)
-    log('per-launch event profile done')
-    peak = 2500.0 if args.dtype == 'bf16' else 157.3
-    # every launch that is MFMA GEMM work: the 3x3x3 kernel, the generic / LDS-DMA pointwise kernels, conv_in, conv_out, the ResidualUnit 1x1x1 + pooling
-    conv = [r for r in rows if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_in', 'mv2_conv_out', 'mv2_conv3', 'mv2_pw_se')]
-    k3 = [r for r in rows if r['what'] == 'mv2_conv3']      # incl. the fused '.k3+k1' launches (their FLOPs include the 1x1x1)
-    conv_ms, conv_flops = sum(r['ms'] for r in conv), sum(r['flops'] for r in conv)
-    k3_ms, k3_flops = sum(r['ms'] for r in k3), sum(r['flops'] for r in k3)
-    k3_flops_exec = sum(r['flops_exec'] for r in k3)
-    all_ms = sum(r['ms'] for r in rows)
-    achieved = k3_flops / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
-    achieved_exec = k3_flops_exec / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
-    all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # HBM-side bytes per conv3 launch: from the committed rocprofv3 --pmc passes of THIS command (not collectable in-process).  The file is
-    # stamped with a hash of the kernel sources it was measured on; a stale file is not printed.
-    traffic, traffic_source = None, None
-    tf = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
-    if os.path.exists(tf) and args.dtype == 'bf16' and B == 1 and cfg_id == 1:
-        try:
-            js = json.load(open(tf))
-            if js.get('kernel_source_sha256') == kernel_source_hash():
-                traffic = js.get('conv3_kernel_hbm_bytes_per_launch')
-                traffic_source = 'profiles/r04_traffic.json (rocprofv3 --pmc passes of this command on these kernel sources: tools/gpu_profile.sh)'
-            else:
-                traffic_source = 'profiles/r04_traffic.json is stale (measured on other kernel sources): not printed'
-        except Exception:
-            traffic = None
-    # encode path alone (north_star names it): MFMA and HBM fractions from the same event table; algorithmic bytes per SURVEY.md §8(d)
-    enc_n = len(tok._plan(B, T)[0].enc_steps)
-    enc_rows = rows[:enc_n]
-    enc_ms, enc_flops = sum(r['ms'] for r in enc_rows), sum(r['flops'] for r in enc_rows)
-    enc_bytes = (365e6 * B + 119e6) if cfg_id in (1, 2) else None
-    encode_path = dict(launches=enc_n, ms=round(enc_ms, 4), flops=enc_flops,
-                       mfma_frac=round(enc_flops / (enc_ms * 1e-3) / 1e12 / peak, 4) if enc_ms > 0 else None,
-                       hbm_frac=round(enc_bytes / (enc_ms * 1e-3) / 6.3e12, 4) if (enc_bytes and enc_ms > 0) else None,
-                       algorithmic_bytes=enc_bytes, hbm_peak='6.3 TB/s achievable (8.0 spec)')
-    roofline = dict(bound='mfma', kernel='conv3p_kernel (mv2_conv3: ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
-                    achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4),
-                    # frac counts ALGORITHMIC flops (2*M*Cout*K: the reference multiplies the causal zero padding); frac_executed
-                    # counts what the matrix pipe executes (the kernel skips the taps in the causal front: 5 / 10 / 20 % at T = 20 / 10 / 5)
-                    achieved_executed=round(achieved_exec, 2), frac_executed=round(achieved_exec / peak, 4), traffic=traffic,
-                    traffic_source=traffic_source, launches=len(k3), flops_per_launch=k3_flops / max(len(k3), 1),
-                    avg_launch_ms=round(k3_ms / max(len(k3), 1), 5),
-                    avg_launch_authority='profiles/r04_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
-                                         'the in-process figure issues every launch 5x back to back between two HIP events (L2/MALL-warm repeats)',
-                    encode_path=encode_path,
-                    all_conv_launches=dict(launches=len(conv), flops_per_step=conv_flops, ms_per_step=round(conv_ms, 4),
-                                           achieved=round(all_conv, 2), frac=round(all_conv / peak, 4)),
-                    all_kernels_ms_per_step=round(all_ms, 4), graph_nodes=len(rows))
-    if args.breakdown:
-        os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
-        agg = {}
-        for r in rows:
-            a = agg.setdefault(r['label'] if r['what'] in ('mv2_conv', 'mv2_conv_rms', 'mv2_conv_out', 'mv2_conv3') else r['what'], dict(ms=0.0, flops=0.0, n=0))
-            a['ms'] += r['ms']; a['flops'] += r['flops']; a['n'] += 1
-        json.dump(dict(rows=rows, by_label=agg), open(args.breakdown, 'w'), indent=1)
+    peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32
+    roofline = None
+    rows = []
+    ops = None
+    if not emu:
+        # ---- roofline of the dominant kernel (rank 0)
+        ops = tok._backend()
+        rows = per_launch_profile(tok, video, ops, tokenize_only)
+        log('per-launch event profile done')
+        c3 = conv3_summary(rows, peak)
+        all_ms = sum(r['ms'] for r in rows)
+        # HBM-side bytes per conv3 launch: from the committed rocprofv3 --pmc passes of THIS command (not collectable in-process).  The file is
+        # stamped with a hash of the kernel sources it was measured on; a stale file is not printed.
+        traffic, traffic_source = None, None
+        for tag in ('r05', 'r04'):
+            tf = os.path.join(ROOT, 'profiles', f'{tag}_traffic.json')
+            if not (os.path.exists(tf) and args.dtype == 'bf16' and B == 1 and cfg_id == 1):
+                continue
+            try:
+                js = json.load(open(tf))
+                if js.get('kernel_source_sha256') == kernel_source_hash():
+                    traffic = js.get('conv3_kernel_hbm_bytes_per_launch')
+                    traffic_source = f'profiles/{tag}_traffic.json (rocprofv3 --pmc passes of this command on these kernel sources: tools/gpu_profile.sh)'
+                    break
+                traffic_source = f'profiles/{tag}_traffic.json is stale (measured on other kernel sources): not printed'
+            except Exception:
+                traffic = None
+        # encode path alone (north_star names it): MFMA and HBM fractions from the same event table; algorithmic bytes per SURVEY.md §8(d)
+        enc_n = len(tok._plan(B, T)[0].enc_steps)
+        enc_rows = rows[:enc_n]
+        enc_ms, enc_flops = sum(r['ms'] for r in enc_rows), sum(r['flops'] for r in enc_rows)
+        enc_bytes = (365e6 * B + 119e6) if cfg_id in (1, 2) else None
+        encode_path = dict(launches=enc_n, ms=round(enc_ms, 4), flops=enc_flops,
+                           mfma_frac=round(enc_flops / (enc_ms * 1e-3) / 1e12 / peak, 4) if enc_ms > 0 else None,
+                           hbm_frac=round(enc_bytes / (enc_ms * 1e-3) / 6.3e12, 4) if (enc_bytes and enc_ms > 0) else None,
+                           algorithmic_bytes=enc_bytes, hbm_peak='6.3 TB/s achievable (8.0 spec)', timing='warm_repeat_events')
+        roofline = dict(bound='mfma', kernel='conv3p_kernel (mv2_conv3: ResidualUnit CausalConv3d k3, reference magvit2_pytorch.py:937)',
+                        achieved=c3['achieved'], peak=peak, unit='TFLOP/s', frac=c3['frac'],
+                        # frac counts ALGORITHMIC flops (2*M*Cout*K: the reference multiplies the causal zero padding); frac_executed
+                        # counts what the matrix pipe executes (the kernel skips the taps in the causal front: 5 / 10 / 20 % at T = 20 / 10 / 5)
+                        achieved_executed=c3['achieved_executed'], frac_executed=c3['frac_executed'], traffic=traffic,
+                        traffic_source=traffic_source, launches=c3['launches'], flops_per_launch=c3['flops_per_launch'],
+                        avg_launch_ms=c3['avg_launch_ms'],
+                        avg_launch_authority='profiles/r05_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
+                                             'the in-process figure issues every launch 5x back to back between two HIP events (L2/MALL-warm repeats: '
+                                             'short launches read warm operands; cold per-launch figures are in the rocprofv3 csv and tools/k3_bench logs)',
+                        encode_path=encode_path,
+                        all_conv_launches=family_summary(rows, GEMM_WHATS, peak),
+                        # every MFMA GEMM launch that is not the 3x3x3 kernel: pointwise / strided convs, feed-forward, conv_in, conv_out, conv1 + pooling
+                        gemm_family_non_conv3=family_summary(rows, GEMM_WHATS, peak, exclude=('mv2_conv3',)),
+                        all_kernels_ms_per_step=round(all_ms, 4), graph_nodes=len(rows))
+        if args.breakdown:
+            os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
+            agg = {}
+            for r in rows:
+                a = agg.setdefault(r['label'] if r['what'] in GEMM_WHATS else r['what'], dict(ms=0.0, flops=0.0, n=0))
+                a['ms'] += r['ms']; a['flops'] += r['flops']; a['n'] += 1
+            json.dump(dict(rows=rows, by_label=agg), open(args.breakdown, 'w'), indent=1)
+
+    extra_legs = world == 1 and cfg_id == 1 and args.dtype == 'bf16' and not emu
 
     # ---- configs[2]'s per-GPU shape (4 clips per step) on the same line: the multi-GPU runs use this shape per rank, and a skipped
     # SCALE record leaves it without driver-timed evidence otherwise
     batch4 = None
-    if world == 1 and cfg_id == 1 and args.dtype == 'bf16' and not args.no_batch4:
+    if extra_legs and not args.no_batch4:
         v4 = torch.randn(4, 3, T, 128, 128, generator=torch.Generator().manual_seed(7)).to(dev)
+        f4 = lambda: tok(v4, return_codes=True, return_recon=True)
         for _ in range(4):
-            tok(v4, return_codes=True, return_recon=True)
-        torch.cuda.synchronize(dev)
+            f4()
         n4 = max(20, min(args.steps, 100))
-        t1 = time.perf_counter()
-        for _ in range(n4):
-            c4, r4 = tok(v4, return_codes=True, return_recon=True)
-        torch.cuda.synchronize(dev)
-        e4 = time.perf_counter() - t1
+        e4, (c4, r4) = timed(f4, n4, sync)
         rows4 = per_launch_profile(tok, v4, ops)
-        k34 = [r for r in rows4 if r['what'] == 'mv2_conv3']
-        k34_ms = sum(r['ms'] for r in k34)
-        a4 = sum(r['flops'] for r in k34) / (k34_ms * 1e-3) / 1e12 if k34_ms > 0 else 0.0
-        a4x = sum(r['flops_exec'] for r in k34) / (k34_ms * 1e-3) / 1e12 if k34_ms > 0 else 0.0
+        c34 = conv3_summary(rows4, peak)
         batch4 = dict(workload='BASELINE configs[2] per-GPU shape: (4,3,17,128,128), forward(return_codes, return_recon), HIP graph',
-                      steps=n4, ms_per_step=round(e4 / n4 * 1e3, 4), frames_per_s=round(4 * T * n4 / e4, 1),
-                      conv3=dict(achieved=round(a4, 2), frac=round(a4 / peak, 4), frac_executed=round(a4x / peak, 4),
-                                 avg_launch_ms=round(k34_ms / max(len(k34), 1), 5), launches=len(k34)),
+                      steps=n4, ms_per_step=round(e4 * 1e3, 4), frames_per_s=round(4 * T / e4, 1),
+                      conv3=dict(achieved=c34['achieved'], frac=c34['frac'], frac_executed=c34['frac_executed'],
+                                 avg_launch_ms=c34['avg_launch_ms'], launches=c34['launches']),
+                      gemm_family_non_conv3=family_summary(rows4, GEMM_WHATS, peak, exclude=('mv2_conv3',)),
                       all_kernels_ms_per_step=round(sum(r['ms'] for r in rows4), 4))
         assert torch.isfinite(r4).all()
         del v4, c4, r4
         log(f'batch-4 leg: {batch4["ms_per_step"]} ms/step, conv3 frac {batch4["conv3"]["frac"]}')
 
+    # ---- BASELINE configs[3] and configs[4] on the driver's line: their own tokenizers, a few steps each
+    configs3 = configs4 = None
+    if extra_legs and not args.no_configs34:
+        try:
+            kw3, B3, T3, size3, _, what3 = workload(3)
+            tok3, _, _ = make_tokenizer(kw3, dev, args.dtype, not args.no_graph)
+            v3 = torch.randn(B3, 3, T3, size3, size3, generator=torch.Generator().manual_seed(11)).to(dev)
+            f3 = lambda: tok3(v3, return_codes=True, return_recon=True)
+            for _ in range(3):
+                f3()
+            n3 = 8
+            e3, (c3_, r3_) = timed(f3, n3, sync)
+            assert torch.isfinite(r3_).all()
+            rows3 = per_launch_profile(tok3, v3, tok3._backend())
+            c33 = conv3_summary(rows3, peak)
+            # the MFMA flash-attention kernel (attn.hip: attn_mfma_kernel, reference attend.py:186-243 behind magvit2_pytorch.py:444-464):
+            # the non-causal space-attention launches, 1024 queries x (1024 + 4 memory) keys per frame and head
+            att = [r for r in rows3 if r['what'] == 'mv2_attention' and r['label'].endswith('.attn')]
+            sp = sorted(att, key=lambda r: -r['flops'])[:2]            # the two attend_space launches (encoder + decoder)
+            sp_ms, sp_fl = sum(r['ms'] for r in sp), sum(r['flops'] for r in sp)
+            a_att = sp_fl / (sp_ms * 1e-3) / 1e12 if sp_ms > 0 else 0.0
+            configs3 = dict(workload=f'{what3}; ({B3},3,{T3},{size3},{size3}) per GPU, HIP graph', steps=n3, ms_per_step=round(e3 * 1e3, 3),
+                            frames_per_s=round(B3 * T3 / e3, 1),
+                            conv3=dict(achieved=c33['achieved'], frac=c33['frac'], frac_executed=c33['frac_executed'],
+                                       avg_launch_ms=c33['avg_launch_ms'], launches=c33['launches']),
+                            attention=dict(kernel='attn_mfma_kernel (mv2_attention, non-causal, 1024 queries x 1028 keys, 8 heads x 32, 144 frames)',
+                                           bound='mfma', launches=len(sp), flops_per_launch=sp_fl / max(len(sp), 1),
+                                           avg_launch_ms=round(sp_ms / max(len(sp), 1), 5), achieved=round(a_att, 2), peak=peak, unit='TFLOP/s',
+                                           frac=round(a_att / peak, 4), flops='QK^T + PV over the full score matrix: 4 n (n + mem) d per head and frame',
+                                           timing='warm_repeat_events'),
+                            gemm_family_non_conv3=family_summary(rows3, GEMM_WHATS, peak, exclude=('mv2_conv3',)),
+                            all_kernels_ms_per_step=round(sum(r['ms'] for r in rows3), 3), graph_nodes=len(rows3))
+            del tok3, v3, c3_, r3_
+            torch.cuda.empty_cache()
+            log(f'configs[3] leg: {configs3["ms_per_step"]} ms/step, attention frac {configs3["attention"]["frac"]}')
+        except Exception as e:                      # an extra leg must never cost the headline line
+            configs3 = dict(error=repr(e)[:300])
+        try:
+            kw4, B4, T4, size4, _, what4 = workload(4)
+            tok4, _, _ = make_tokenizer(kw4, dev, args.dtype, not args.no_graph)
+            v4f = torch.randn(B4, 3, T4, size4, size4, generator=torch.Generator().manual_seed(12)).to(dev)
+            f4f = lambda: tok4.tokenize(v4f)
+            for _ in range(3):
+                f4f()
+            n4f = 30
+            e4f, ids4 = timed(f4f, n4f, sync)
+            rows4f = per_launch_profile(tok4, v4f, tok4._backend(), tokenize_only=True)
+            c34f = conv3_summary(rows4f, peak)
+            configs4 = dict(workload=f'{what4}; ({B4},3,{T4},{size4},{size4}) per GPU, HIP graph', steps=n4f, ms_per_step=round(e4f * 1e3, 3),
+                            frames_per_s=round(B4 * T4 / e4f, 1), ids_dtype=str(ids4.dtype),
+                            conv3=dict(achieved=c34f['achieved'], frac=c34f['frac'], avg_launch_ms=c34f['avg_launch_ms'], launches=c34f['launches']),
+                            all_kernels_ms_per_step=round(sum(r['ms'] for r in rows4f), 3))
+            del tok4, v4f, ids4
+            torch.cuda.empty_cache()
+            log(f'configs[4] leg: {configs4["ms_per_step"]} ms/step')
+        except Exception as e:
+            configs4 = dict(error=repr(e)[:300])
+
     # ---- the bit-exact mode on the same workload (driver-visible): fp32 storage + fp32 MFMA
     exact = None
-    if world == 1 and cfg_id == 1 and args.dtype == 'bf16' and not args.no_exact:
+    if extra_legs and not args.no_exact:
         tok.compute_dtype = torch.float32
         for _ in range(3):
             c32, r32 = step()
-        torch.cuda.synchronize(dev)
         n32 = 40
-        t1 = time.perf_counter()
-        for _ in range(n32):
-            c32, r32 = step()
-        torch.cuda.synchronize(dev)
-        e32 = time.perf_counter() - t1
-        exact = dict(frames_per_s=round(B * T * n32 / e32, 1), ms_per_step=round(e32 / n32 * 1e3, 3), steps=n32,
+        e32, (c32, r32) = timed(step, n32, sync)
+        exact = dict(frames_per_s=round(B * T / e32, 1), ms_per_step=round(e32 * 1e3, 3), steps=n32,
                      ids_mismatch_vs_bf16_mode=round((c32 != codes).float().mean().item(), 5))
         tok.compute_dtype = torch.bfloat16
         log(f'exact fp32 mode: {exact["ms_per_step"]} ms/step')
 
     # ---- CPU baseline: the oracle restatement on this box's host cores, bounded sample of the same workload
     cpu_baseline = None
-    if not args.no_cpu_baseline and world == 1 and not tokenize_only:
-        from oracle import ref_loader
-        from oracle.restate import OracleTokenizer
-        try:
-            navail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            navail = os.cpu_count() or 1
-        orc = OracleTokenizer(sd, **cfg)
-        vc = video[:1].cpu()
-        # Thread sweep on a SMALL sample ((1,3,5,64,64): a fraction of a second per run), ascending, stopped at the first setting that is
-        # 3x slower than the best so far: torch's CPU convolutions stop scaling well before 256 threads (measured on the GPU box: the
-        # full clip takes 3.6 s on 64 threads and 220 s on 256), so "all cores" is measured, not assumed, and never on the full clip.
-        # The timed full-clip runs use the fastest setting.  MV2_CPU_BASELINE_THREADS pins one setting.
-        pin = os.environ.get('MV2_CPU_BASELINE_THREADS')
-        cand = [int(pin)] if pin else sorted({navail, max(1, navail // 2), max(1, navail // 4), max(1, navail // 8), min(navail, 16)})
-        small = vc[:, :, :5, :64, :64].contiguous()
-        orc_small = OracleTokenizer(sd, **dict(cfg, image_size=64))                    # same weights, 64 x 64 frames
-        sweep = {}
-        for nt in cand:
-            torch.set_num_threads(nt)
-            orc_small(small, return_codes=True, return_recon=True)                    # warm-up at this setting
-            t1 = time.perf_counter()
-            orc_small(small, return_codes=True, return_recon=True)
-            sweep[nt] = round(time.perf_counter() - t1, 4)
-            if sweep[nt] > 3.0 * min(sweep.values()):
-                break
-        ncores = min(sweep, key=sweep.get)
-        torch.set_num_threads(ncores)
-        log(f'cpu baseline: thread sweep on a (1,3,5,64,64) sample (s) {sweep} -> {ncores} threads (cores available: {navail})')
-        t1 = time.perf_counter()
-        oc, orc_recon = orc(vc, return_codes=True, return_recon=True)                 # warm-up on the full clip
-        log(f'cpu baseline: warm-up {time.perf_counter() - t1:.2f} s')
-        t1 = time.perf_counter()
-        oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
-        sweep_full = time.perf_counter() - t1
-        ts = [sweep_full]
-        budget = 20.0                                                              # bounded sample (seconds of CPU wall for the timed runs)
-        while len(ts) < 4 and sum(ts) + ts[-1] < budget:
-            t1 = time.perf_counter()
-            oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
-            ts.append(time.perf_counter() - t1)
-        timed = ts
-        med = sorted(timed)[len(timed) // 2]
-        mism = (codes[:1].cpu() != oc).float().mean().item()
-        derr = (recon[:1].cpu() - orc_recon).abs().mean().item()
-        cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=ncores, cores_available=navail, kind='port',
-                            thread_sweep_small_sample_s={str(k): v for k, v in sweep.items()},
-                            sample=f'1 clip (1,3,{T},128,128) fp32, {len(timed)} timed run(s) after warm-up, median {med:.2f} s/clip '
-                                   f'(bounded to ~{budget:.0f} s of CPU time)',
-                            ids_mismatch_vs_gpu=round(mism, 5), recon_mean_abs_diff_vs_gpu=round(derr, 6))
-        # The reference's OWN code (magvit2_pytorch.py:1656-1720 forward) when the build-time copy oracle/_ref is on this box: it becomes
-        # the reported baseline (kind "reference"); the port's figure stays beside it.  Same clip, same thread count, same bound.
-        if ref_loader.reference_available():
-            try:
-                ref = ref_loader.make_reference_tokenizer(**kw)
-                ref.load_state_dict(sd, strict=False)
-                with torch.no_grad():
-                    t1 = time.perf_counter()
-                    rc, rr = ref(vc, return_codes=True, return_recon=True)            # warm-up
-                    log(f'cpu baseline (reference itself, {ref_loader.reference_origin()}): warm-up {time.perf_counter() - t1:.2f} s')
-                    tr = []
-                    while len(tr) < 3 and (not tr or sum(tr) + tr[-1] < budget):
-                        t1 = time.perf_counter()
-                        rc, rr = ref(vc, return_codes=True, return_recon=True)
-                        tr.append(time.perf_counter() - t1)
-                medr = sorted(tr)[len(tr) // 2]
-                cpu_baseline.update(
-                    kind='reference', port_value=cpu_baseline['value'], value=round(T / medr, 3),
-                    source=f'{ref_loader.reference_origin()}: VideoTokenizer.forward(return_codes=True, return_recon=True), magvit2_pytorch.py:1656-1720, '
-                           'loaded under the sys.modules shims of oracle/ref_loader.py (LFQ / Taylor attention from oracle/thirdparty.py: those packages are not vendored)',
-                    sample=f'1 clip (1,3,{T},128,128) fp32, {len(tr)} timed run(s) of the reference after warm-up, median {medr:.2f} s/clip; '
-                           f'the port (oracle/restate.py): {len(timed)} run(s), median {med:.2f} s/clip (each bounded to ~{budget:.0f} s of CPU time)',
-                    reference_ids_equal_port=bool(torch.equal(rc, oc)), reference_recon_max_abs_diff_vs_port=round((rr - orc_recon).abs().max().item(), 8),
-                    ids_mismatch_vs_gpu=round((codes[:1].cpu() != rc).float().mean().item(), 5),
-                    recon_mean_abs_diff_vs_gpu=round((recon[:1].cpu() - rr).abs().mean().item(), 6))
-            except Exception as e:                                                  # the port's figure stands
-                cpu_baseline['reference_error'] = str(e)[:300]
-        if exact is not None:
-            exact['ids_mismatch_vs_cpu_oracle'] = round((c32[:1].cpu() != oc).float().mean().item(), 5)
-            exact['recon_max_abs_diff_vs_cpu_oracle'] = round((r32[:1].cpu() - orc_recon).abs().max().item(), 7)
-        # the oracle's own bf16-autocast drift against its fp32: the yardstick for the bf16 GPU path's tolerance
-        try:
-            with torch.autocast('cpu', dtype=torch.bfloat16):
-                bc, brecon = orc(vc, return_codes=True, return_recon=True)
-            cpu_baseline['bf16_autocast'] = dict(ids_mismatch_vs_fp32=round((bc != oc).float().mean().item(), 5),
-                                                 recon_mean_abs=round((brecon.float() - orc_recon).abs().mean().item(), 6))
-        except Exception as e:                                                      # never let the yardstick kill the bench line
-            cpu_baseline['bf16_autocast'] = dict(error=str(e)[:200])
+    if not args.no_cpu_baseline and world == 1 and not tokenize_only and not emu:
+        cpu_baseline = cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, (c32, r32) if exact is not None else None)
 
     out = dict(
         metric='video frames/sec encode+decode, 128x128x17f' if not tokenize_only else 'video frames/sec tokenize(), 128x128x65f FSQ',
         value=round(value, 2), unit='frames/s', n_gpus=world,
         steps=args.steps, warmup=warm, soak_steps=soak_steps, ms_per_step=round(el / args.steps * 1e3, 4), timed_seconds=round(el, 3),
-        higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
-        config=dict(workload=f'{what}; ({B},3,{T},128,128) clip(s) per GPU, README layer spec, random-init weights seed 0',
+        higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype if not emu else 'f32 (emulation dry run)', data='synthetic',
+        config=dict(workload=f'{what}; ({B},3,{T},{size},{size}) clip(s) per GPU, README layer spec, random-init weights seed 0',
                     global_batch=B * world, frames_per_clip=T, parallelism=f'dp{world} (clip sharding, no data-path collective)',
                     hip_graph=not args.no_graph),
-        roofline=roofline, batch4=batch4, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+        roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+    if emu:
+        out['dry_run_backend'] = 'emulation'
     if world > 1:
         out['rccl_ranks'] = rccl_ranks
         out['per_rank_ms_per_step'] = rank_ms
+        # The same-shape single-GPU base of this line.  Clips shard with no data-path collective, so a rank's own
+        # ms/step IS the one-GPU time of this per-GPU shape on its device; the base is rank 0's.  The N = 1 DEFAULT line runs configs[1]
+        # (1 clip per GPU, lower per-GPU throughput), so value(N) / value(1) of the default lines overstates scaling: use this base (or the
+        # `batch4` object of the N = 1 line, the same shape timed by the driver's own N = 1 run).
+        base = B * T / (rank_ms[0] * 1e-3)
+        out['weak_scaling_base'] = dict(per_gpu_batch=B, frames_per_clip=T, n1_frames_per_s_same_shape=round(base, 1),
+                                        source="rank 0's own ms/step of this run (per_rank_ms_per_step[0]); cross-check: `batch4.frames_per_s` of the N = 1 line"
+                                        if cfg_id == 2 and B == 4 else "rank 0's own ms/step of this run (per_rank_ms_per_step[0])",
+                                        efficiency_vs_same_shape=round(value / (world * base), 4),
+                                        note='value / (N x n1_frames_per_s_same_shape); do not divide by the N = 1 default line (configs[1], 1 clip per GPU)')
+    else:
+        out['scaling_curve'] = dict(measured=False, note='world size 1: no multi-GPU point in this run; the N > 1 default is configs[2] '
+                                    '(4 clips per GPU) and its same-shape single-GPU base is the `batch4` object of this line')
     print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, exact_out):
+    """the reference's own forward (oracle/_ref) and the port (oracle/restate.py) on this box's host cores, bounded sample"""
+    import torch
+    from oracle import ref_loader
+    from oracle.restate import OracleTokenizer
+    try:
+        navail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        navail = os.cpu_count() or 1
+    orc = OracleTokenizer(sd, **cfg)
+    vc = video[:1].cpu()
+    # Thread sweep on a SMALL sample ((1,3,5,64,64): a fraction of a second per run), ascending, stopped at the first setting that is
+    # 3x slower than the best so far: torch's CPU convolutions stop scaling well before 256 threads (measured on the GPU box: the
+    # full clip takes 3.6 s on 64 threads and 220 s on 256), so "all cores" is measured, not assumed, and never on the full clip.
+    # The timed full-clip runs use the fastest setting.  MV2_CPU_BASELINE_THREADS pins one setting.
+    pin = os.environ.get('MV2_CPU_BASELINE_THREADS')
+    cand = [int(pin)] if pin else sorted({navail, max(1, navail // 2), max(1, navail // 4), max(1, navail // 8), min(navail, 16)})
+    small = vc[:, :, :5, :64, :64].contiguous()
+    orc_small = OracleTokenizer(sd, **dict(cfg, image_size=64))                    # same weights, 64 x 64 frames
+    sweep = {}
+    for nt in cand:
+        torch.set_num_threads(nt)
+        orc_small(small, return_codes=True, return_recon=True)                    # warm-up at this setting
+        t1 = time.perf_counter()
+        orc_small(small, return_codes=True, return_recon=True)
+        sweep[nt] = round(time.perf_counter() - t1, 4)
+        if sweep[nt] > 3.0 * min(sweep.values()):
+            break
+    ncores = min(sweep, key=sweep.get)
+    torch.set_num_threads(ncores)
+    log(f'cpu baseline: thread sweep on a (1,3,5,64,64) sample (s) {sweep} -> {ncores} threads (cores available: {navail})')
+    t1 = time.perf_counter()
+    oc, orc_recon = orc(vc, return_codes=True, return_recon=True)                 # warm-up on the full clip
+    log(f'cpu baseline: warm-up {time.perf_counter() - t1:.2f} s')
+    t1 = time.perf_counter()
+    oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
+    ts = [time.perf_counter() - t1]
+    budget = 20.0                                                              # bounded sample (seconds of CPU wall for the timed runs)
+    while len(ts) < 4 and sum(ts) + ts[-1] < budget:
+        t1 = time.perf_counter()
+        oc, orc_recon = orc(vc, return_codes=True, return_recon=True)
+        ts.append(time.perf_counter() - t1)
+    timed_ = ts
+    med = sorted(timed_)[len(timed_) // 2]
+    mism = (codes[:1].cpu() != oc).float().mean().item()
+    derr = (recon[:1].cpu() - orc_recon).abs().mean().item()
+    cpu_baseline = dict(value=round(T / med, 3), unit='frames/s', cores=ncores, cores_available=navail, kind='port',
+                        thread_sweep_small_sample_s={str(k): v for k, v in sweep.items()},
+                        sample=f'1 clip (1,3,{T},128,128) fp32, {len(timed_)} timed run(s) after warm-up, median {med:.2f} s/clip '
+                               f'(bounded to ~{budget:.0f} s of CPU time)',
+                        ids_mismatch_vs_gpu=round(mism, 5), recon_mean_abs_diff_vs_gpu=round(derr, 6))
+    # The reference's OWN code (magvit2_pytorch.py:1656-1720 forward) when the build-time copy oracle/_ref is on this box: it becomes
+    # the reported baseline (kind "reference"); the port's figure stays beside it.  Same clip, same thread count, same bound.
+    if ref_loader.reference_available():
+        try:
+            ref = ref_loader.make_reference_tokenizer(**kw)
+            ref.load_state_dict(sd, strict=False)
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                rc, rr = ref(vc, return_codes=True, return_recon=True)            # warm-up
+                log(f'cpu baseline (reference itself, {ref_loader.reference_origin()}): warm-up {time.perf_counter() - t1:.2f} s')
+                tr = []
+                while len(tr) < 3 and (not tr or sum(tr) + tr[-1] < budget):
+                    t1 = time.perf_counter()
+                    rc, rr = ref(vc, return_codes=True, return_recon=True)
+                    tr.append(time.perf_counter() - t1)
+            medr = sorted(tr)[len(tr) // 2]
+            cpu_baseline.update(
+                kind='reference', port_value=cpu_baseline['value'], value=round(T / medr, 3),
+                source=f'{ref_loader.reference_origin()}: VideoTokenizer.forward(return_codes=True, return_recon=True), magvit2_pytorch.py:1656-1720, '
+                       'loaded under the sys.modules shims of oracle/ref_loader.py (LFQ / Taylor attention from oracle/thirdparty.py: those packages are not vendored)',
+                sample=f'1 clip (1,3,{T},128,128) fp32, {len(tr)} timed run(s) of the reference after warm-up, median {medr:.2f} s/clip; '
+                       f'the port (oracle/restate.py): {len(timed_)} run(s), median {med:.2f} s/clip (each bounded to ~{budget:.0f} s of CPU time)',
+                reference_ids_equal_port=bool(torch.equal(rc, oc)), reference_recon_max_abs_diff_vs_port=round((rr - orc_recon).abs().max().item(), 8),
+                ids_mismatch_vs_gpu=round((codes[:1].cpu() != rc).float().mean().item(), 5),
+                recon_mean_abs_diff_vs_gpu=round((recon[:1].cpu() - rr).abs().mean().item(), 6))
+        except Exception as e:                                                  # the port's figure stands
+            cpu_baseline['reference_error'] = str(e)[:300]
+    if exact is not None and exact_out is not None:
+        c32, r32 = exact_out
+        exact['ids_mismatch_vs_cpu_oracle'] = round((c32[:1].cpu() != oc).float().mean().item(), 5)
+        exact['recon_max_abs_diff_vs_cpu_oracle'] = round((r32[:1].cpu() - orc_recon).abs().max().item(), 7)
+    # the oracle's own bf16-autocast drift against its fp32: the yardstick for the bf16 GPU path's tolerance
+    try:
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            bc, brecon = orc(vc, return_codes=True, return_recon=True)
+        cpu_baseline['bf16_autocast'] = dict(ids_mismatch_vs_fp32=round((bc != oc).float().mean().item(), 5),
+                                             recon_mean_abs=round((brecon.float() - orc_recon).abs().mean().item(), 6))
+    except Exception as e:                                                      # never let the yardstick kill the bench line
+        cpu_baseline['bf16_autocast'] = dict(error=str(e)[:200])
+    return cpu_baseline
 
 
 if __name__ == '__main__':

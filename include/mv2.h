@@ -261,7 +261,7 @@ int mv2_attention(int dtype, const void* qkv, const float* mem_kv, void* out, in
  *   kv   : per (frame, chunk, head) partial sums over tokens of phi(k)^T [v, 1]  -> part (fp32)
  *          part[((f*nchunk + j)*heads + h)*657], 657 = 73*9.  nchunk == 1: one workgroup per (frame, head) walks the whole frame and
  *          `part` receives the FINISHED states [frames][heads][657] (no partial states in memory, nothing to reduce).
- *   apply: reduces the chunks (nchunk > 1; into kvsum_ws, which is not touched for nchunk == 1),
+ *   apply: reduces the chunks (nchunk > 1; into kvsum_ws, which is not touched and may be NULL for nchunk == 1),
  *          out = phi(q * d^-1/2) . KV / max(phi(q) . Ksum, 1e-5)
  * q: rows x (heads*8); kv: rows x (2*heads*8) with k first; out: rows x (heads*8).
  * ------------------------------------------------------------------------------------------- */

@@ -21,7 +21,9 @@ LIB = os.path.join(HERE, 'libmv2_hip.so')
 SOURCES = ['conv.hip', 'conv3.hip', 'conv3p.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
 # experiments library (tools/ only, -DMV2_EXPERIMENTS): the same sources with phase-clock profiling and the conv3 work-split knobs
 LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
-SOURCES_EXP = SOURCES + ['exp_se.hip', 'exp_attn.hip']      # + kernels that exist only to be measured (tools/)
+# + kernels that exist only to be measured: they live with the other experiments under tools/experiments/, not in the product source directory
+EXP_DIR = os.path.join(HERE, '..', 'tools', 'experiments')
+SOURCES_EXP = SOURCES + [os.path.join(EXP_DIR, 'exp_se.hip'), os.path.join(EXP_DIR, 'exp_attn.hip')]
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv3p.h'),
            os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
@@ -49,14 +51,14 @@ def build(force=False, verbose=True, experiments=False):
     hipcc = _hipcc()
     jobs = []
     for s in sources:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace('.hip', '.o'))
+        src = s if os.path.isabs(s) else os.path.join(CSRC, s)
+        obj = os.path.join(objdir, os.path.basename(s).replace('.hip', '.o'))
         if force or _stale(obj, [src] + HEADERS):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *flags, '-c', src, '-o', obj]
+        cmd = [hipcc, *flags, '-I', CSRC, '-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
@@ -67,7 +69,7 @@ def build(force=False, verbose=True, experiments=False):
             print(f'[mv2 build] compiling {len(jobs)} file(s) for gfx950 ...', flush=True)
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(cc, jobs))
-    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in sources]
+    objs = [os.path.join(objdir, os.path.basename(s).replace('.hip', '.o')) for s in sources]
     if force or jobs or _stale(lib, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib]
         r = subprocess.run(cmd, capture_output=True, text=True)

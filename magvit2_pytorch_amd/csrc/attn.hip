@@ -590,7 +590,7 @@ extern "C" int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames,
 
 extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames, int n,
                                 int heads, int nchunk, void* stream) {
-    if (!q || !part || !out || !kvsum_ws || frames <= 0 || n <= 0 || heads <= 0 || 256 % heads != 0) return MV2_EINVAL;
+    if (!q || !part || !out || (nchunk > 1 && !kvsum_ws) || frames <= 0 || n <= 0 || heads <= 0 || 256 % heads != 0) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
     const size_t lds = (size_t)heads * TAY_F * TAY_LP * sizeof(float);
     if (lds > 64 * 1024) return MV2_EINVAL;

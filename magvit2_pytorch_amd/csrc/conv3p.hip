@@ -667,7 +667,9 @@ Plan3P conv3p_plan(const mv2_conv_desc& d) {
     P.splitk = (int)s;
     P.nA = P.tilesA = P.SB = P.tiles_per_xcd = 0;
     P.grid = P.n_tiles * P.splitk;
-    // Two-class list: the launch fits the slots once (slots / 2 <= tiles < slots) and the slot count is a multiple of 8.  The first
+    // Two-class list: the launch fits the slots once (slots / 8 <= tiles < slots: the measured regime below includes C = 512 at T = 20 with
+    // 320 tiles for 768 slots; the per-split checks inside the loop - at least six groups per part, whole slot layers per class - are what
+    // keeps T = 10 / T = 5 on the uniform rule) and the slot count is a multiple of 8.  The first
     // tiles in S0 parts, the last nB tiles in 2 S0 parts, with S0 (tiles + nB) == slots: every CU receives the same number of groups
     // instead of 3 against 2 tiles (C = 256 at batch 1: S0 = 1, 512 + 128 tiles; C = 512, T = 20: S0 = 2, 256 + 64 tiles).  Only where the
     // shorter parts keep at least six groups (a part pays ~10k clocks of fixed phases) and every count divides over the 8 XCDs; measured

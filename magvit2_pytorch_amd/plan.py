@@ -614,9 +614,15 @@ class Plan:
         mem = pm.f32[pre + '.mem_kv']
         hw = x.H * x.W
         if time_axis:
-            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, x.B * hw, x.T, heads, dh, mem.shape[2], True, hw, x.T * hw, hw))
+            nseq, ntok = x.B * hw, x.T
+            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, nseq, ntok, heads, dh, mem.shape[2], True, hw, x.T * hw, hw))
         else:
-            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, x.B * x.T, hw, heads, dh, mem.shape[2], False, 1, hw, 1))
+            nseq, ntok = x.B * x.T, hw
+            steps.append(ops.attention(self.dt, qkv.t, mem, ao.t, nseq, ntok, heads, dh, mem.shape[2], False, 1, hw, 1))
+        steps[-1].label = pre + '.attn'
+        # algorithmic FLOPs of sim = q k^T and out = attn v over the full (n, n + mem) score matrix (the reference computes the causal
+        # half too and masks it, attend.py:225-243)
+        self.step_flops[id(steps[-1])] = 4.0 * nseq * heads * ntok * (ntok + mem.shape[2]) * dh
         self.step_names.append('attention')
         self.arena.put(qkv.t)
         out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], ao, residual=x, check_bounds=False)
@@ -645,16 +651,20 @@ class Plan:
         kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
         frames, n = x.B * x.T, x.H * x.W
         # one workgroup per (frame, head) accumulates the whole frame's state (mv2_taylor_kv with nchunk = 1): no partial states in HBM and no
-        # reduce launch (the chunked form, nchunk > 1, stays in the ABI for frames too long for one workgroup's patience)
-        nchunk = 1
+        # reduce launch.  Only where frames x heads leaves most of the chip idle (single images, one or two frames) does the chunked form
+        # (nchunk > 1: partial states + reduce) pay: measured 21.5 -> 10.5 us at 3 frames x 2100 tokens, slower from 20 frames on
+        # (profiles/r04_findings.md section 13)
+        fh, cus = frames * heads, int(getattr(ops, 'cus', 256))
+        nchunk = 1 if 2 * fh >= cus else max(1, min(-(-cus // fh), n // 32))
         part = self.arena.get(frames * nchunk * heads * 657, torch.float32)
-        kvsum = self.arena.get(frames * heads * 657, torch.float32)
+        kvsum = self.arena.get(frames * heads * 657, torch.float32) if nchunk > 1 else None
         o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
         steps.append(ops.taylor_kv(self.dt, kv.t, part, frames, n, heads, nchunk))
         steps.append(ops.taylor_apply(self.dt, q.t, part, o.t, kvsum, frames, n, heads, nchunk))
         self.step_names += ['taylor_kv', 'taylor_apply']
         for t in (part, kvsum, q.t, kv.t):
-            self.arena.put(t)
+            if t is not None:
+                self.arena.put(t)
         out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], o, residual=x, check_bounds=False)
         self.arena.put(o.t)
         self.arena.put(x.t)

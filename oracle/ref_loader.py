@@ -34,10 +34,13 @@ REF_FILES = ('magvit2_pytorch.py', 'attend.py', 'version.py')
 
 
 def _resolve_root():
-    cands = [os.environ.get('MV2_REFERENCE_ROOT'), '/root/reference', REF_COPY_ROOT]
+    env = os.environ.get('MV2_REFERENCE_ROOT')
+    cands = [env, '/root/reference', REF_COPY_ROOT]
     for c in cands:
         if c and os.path.isfile(os.path.join(c, 'magvit2_pytorch', 'magvit2_pytorch.py')):
             return c
+        if c and c is env:
+            warnings.warn(f'MV2_REFERENCE_ROOT={env!r} does not contain magvit2_pytorch/magvit2_pytorch.py: ignored')
     return '/root/reference'
 
 
@@ -65,7 +68,16 @@ def place_reference_copy(src_root='/root/reference') -> bool:
     os.makedirs(dst, exist_ok=True)
     for f in REF_FILES:
         shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    _refresh_root()
     return True
+
+
+def _refresh_root():
+    """re-resolve the reference root (the module constants were fixed at import, so a process that placed the copy itself kept
+    pointing at a missing /root/reference)"""
+    global REFERENCE_ROOT, _PKG_DIR
+    REFERENCE_ROOT = _resolve_root()
+    _PKG_DIR = os.path.join(REFERENCE_ROOT, 'magvit2_pytorch')
 
 
 def _stub(name, **attrs):

@@ -1074,3 +1074,58 @@ def test_lowering_options_are_explicit_not_environment(monkeypatch):
     with pytest.raises(ValueError):
         with plan_mod.lowering_options(convin_cpad=5):
             pass
+
+
+def _run_bench(*argv):
+    """bench.py as the driver starts it (a fresh interpreter), on the CPU emulation: the control path end to end"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv, '--dry-run-backend', 'emulation'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-1000:]}'
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_control_path_dry_run():
+    """bench.py's N > 1 path (respawn under torch.distributed.run, 127.0.0.1 rendezvous, barriers around the timed
+    region, per-rank times, gather_codes, destroy_process_group, JSON assembly) must have executed before the driver's first SCALE run.
+    Here it runs with gloo instead of RCCL and the kernel emulation instead of the HIP library; the numbers mean nothing."""
+    js = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '1')
+    assert js['n_gpus'] == 2 and js['rccl_ranks'] == 2 and len(js['per_rank_ms_per_step']) == 2
+    assert js['steps'] == 1 and js['scaling'] == 'weak' and js['higher_is_better'] is True and js['unit'] == 'frames/s'
+    assert js['dry_run_backend'] == 'emulation' and 'DRY RUN' in js['config']['workload']
+    assert 'configs[2]' in js['config']['workload']                           # the N > 1 default shape
+    B, T = js['weak_scaling_base']['per_gpu_batch'], js['weak_scaling_base']['frames_per_clip']
+    assert js['config']['global_batch'] == 2 * B
+    # value = whole-job frames / max-over-ranks time; the same-shape base comes from rank 0's own time
+    assert abs(js['value'] - 2 * B * T / (js['ms_per_step'] * 1e-3)) <= 0.02 * js['value']
+    base = js['weak_scaling_base']['n1_frames_per_s_same_shape']
+    assert abs(base - B * T / (js['per_rank_ms_per_step'][0] * 1e-3)) <= 0.02 * base
+    assert abs(js['weak_scaling_base']['efficiency_vs_same_shape'] - js['value'] / (2 * base)) < 0.02     # `base` is printed rounded to 0.1 frames/s
+    assert js['ms_per_step'] >= max(js['per_rank_ms_per_step']) * 0.999      # the barrier-bracketed time is the max over ranks
+    assert 'scaling_curve' not in js
+
+
+def test_bench_single_rank_dry_run_states_no_curve():
+    js = _run_bench('--steps', '1', '--warmup', '1')
+    assert js['n_gpus'] == 1 and 'rccl_ranks' not in js and 'weak_scaling_base' not in js
+    assert js['scaling_curve']['measured'] is False and 'batch4' in js['scaling_curve']['note']
+    assert 'configs[1]' in js['config']['workload'] and js['config']['global_batch'] == 1
+
+
+def test_bench_workloads_match_baseline_configs():
+    """the shapes bench.py times are the ones BASELINE.json names (configs[1..4])"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('mv2_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    shapes = {c: bench.workload(c)[1:5] for c in (1, 2, 3, 4)}
+    assert shapes == {1: (1, 17, 128, False), 2: (4, 17, 128, False), 3: (4, 33, 256, False), 4: (2, 65, 128, True)}
+    kw4 = bench.workload(4)[0]
+    assert kw4['use_fsq'] and kw4['fsq_levels'] == [8, 5, 5, 5]
+    assert bench.workload(3)[0]['image_size'] == 256 and bench.workload(3)[0]['max_dim'] == 512
+    assert bench.parse(['--config', '3']).config == 3
