@@ -87,6 +87,8 @@ def parse(argv=None):
     ap.add_argument('--no-batch4', action='store_true', help='skip the configs[2] per-GPU-shape leg of the N = 1 line')
     ap.add_argument('--no-configs34', action='store_true', help='skip the configs[3] / configs[4] legs of the N = 1 line')
     ap.add_argument('--breakdown', default='', help='write the per-launch timing table to this json file')
+    ap.add_argument('--lowering', default='', help='A/B only: comma-separated fields of plan.LoweringOptions, e.g. fuse_ff=0,fuse_ff_min_rows=0 '
+                                                   '(the defaults are the product; the line records what was set)')
     ap.add_argument('--dry-run-backend', default='', choices=['', 'emulation'],
                     help='emulation: CPU kernel emulation + gloo + a tiny spec; exercises the control path only (tests)')
     return ap.parse_args(argv)
@@ -224,6 +226,19 @@ def timed(fn, n, sync):
 def main():
     args = parse()
     respawn_if_needed(args)
+    if args.lowering:
+        from magvit2_pytorch_amd import plan as plan_mod
+        kv = {}
+        for item in args.lowering.split(','):
+            k, v = item.split('=')
+            kv[k.strip()] = int(v)
+        kv = {k: (bool(v) if isinstance(getattr(plan_mod.OPTIONS, k), bool) else v) for k, v in kv.items()}
+        with plan_mod.lowering_options(**kv):
+            return _main(args, kv)
+    return _main(args, None)
+
+
+def _main(args, lowering):
     import torch
     from magvit2_pytorch_amd import distributed as D
 
@@ -471,6 +486,8 @@ def main():
                     global_batch=B * world, frames_per_clip=T, parallelism=f'dp{world} (clip sharding, no data-path collective)',
                     hip_graph=not args.no_graph),
         roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+    if lowering:
+        out['lowering_overrides'] = lowering       # A/B run: NOT the product's lowering
     if emu:
         out['dry_run_backend'] = 'emulation'
     if world > 1:

@@ -257,6 +257,28 @@ int mv2_attention(int dtype, const void* qkv, const float* mem_kv, void* out, in
                   int64_t tok_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FeedForward in ONE launch (reference M:466-508 FeedForward = RMSNorm -> Conv3d 1x1x1 (dim -> 2 inner) -> GEGLU -> Conv3d 1x1x1
+ * (inner -> dim), inside Residual M:174, behind TokenShift M:250-253 for the time-axis layers), bf16, C = 256 / 512:
+ *   xs  = x, or with shift_hw > 0 the token-shifted row: channels [C/2, C) from the row shift_hw earlier, zero where
+ *         (row / shift_hw) % T == 0 (rows % (shift_hw * T) == 0)
+ *   h   = bf16( gelu(g) * v ),  [v | g] = (W1 xs) / max(|xs|, 1e-12) + b1      (sqrt(C) * gamma folded into W1's columns)
+ *   out = bf16( W2 h + b2 + x )
+ * w1: the mv2_conv image of the first conv ([C/64 steps][co_pad = ceil128(2 hidden_pad)][128 B], GEGLU column order: block j of 64 packed
+ *     columns = 32 values then 32 gates of hidden units 32 j .. 32 j + 31) in FRAGMENT-MAJOR order (mv2_pack_conv3d's second form);
+ * w2: the image of the second conv with K = hidden_pad ([hidden_pad/64 steps][C][128 B]), fragment-major; b1 (co_pad), b2 (C) fp32 in
+ *     packed column order; hidden_pad % 64 == 0.  The hidden tensor never exists in memory.
+ * Few-row launches split a row tile's hidden range over several workgroups: mv2_ff_workspace_bytes() of fp32 slabs and
+ * mv2_ff_counter_bytes() of ticket words (zero before the first launch; every launch leaves them zero) - both may be 0 / NULL
+ * when the query returns 0.  x != out.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_ff_eligible(int dtype, int64_t rows, int C, int hidden_pad);
+size_t mv2_ff_workspace_bytes(int64_t rows, int C, int hidden_pad);
+size_t mv2_ff_counter_bytes(int64_t rows, int C, int hidden_pad);
+int mv2_ff(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+           int64_t rows, int C, int hidden_pad, int shift_hw, int T, void* workspace, size_t workspace_bytes,
+           void* counters, size_t counter_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Taylor-series linear attention (third-party TaylorSeriesLinearAttn, call site M:430), dim_head 8.
  *   kv   : per (frame, chunk, head) partial sums over tokens of phi(k)^T [v, 1]  -> part (fp32)
  *          part[((f*nchunk + j)*heads + h)*657], 657 = 73*9.  nchunk == 1: one workgroup per (frame, head) walks the whole frame and

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmv2_hip.so')
 # product library: no environment switches, no experimental kernels
-SOURCES = ['conv.hip', 'conv3.hip', 'conv3p.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
+SOURCES = ['conv.hip', 'conv3.hip', 'conv3p.hip', 'convout.hip', 'convin.hip', 'pwse.hip', 'ff.hip', 'misc.hip', 'attn.hip', 'quant.hip', 'pack_host.hip']
 # experiments library (tools/ only, -DMV2_EXPERIMENTS): the same sources with phase-clock profiling and the conv3 work-split knobs
 LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
 # + kernels that exist only to be measured: they live with the other experiments under tools/experiments/, not in the product source directory

@@ -125,14 +125,26 @@ template <> struct Act<BF16> {
     // v_rcp_f32 (1 ulp) instead of a division: without fast-math __fdividef compiles to the full IEEE sequence (2 v_div_scale, v_rcp, Newton
     // steps, v_div_fmas, v_div_fixup: ~10 VALU slots per value in an epilogue whose wave has the SIMD to itself)
     static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+    // gelu(v) = max(v, 0) - 0.5 r(|v|), r(a) = a erfc(a / sqrt 2): the bump r as a degree-10 polynomial in t = 2 a / 4.5 - 1 on [0, 4.5]
+    // (clamped beyond, where r < 1e-5): |error| <= 1.5e-5 absolute in float32 Horner form (tools/gelu_bump_fit.py; coefficients < 1 in
+    // magnitude, no cancellation), i.e. below a 256th of a bf16 ulp wherever |gelu| > 4e-3.  No v_exp / v_rcp (quarter rate): 2 + 12
+    // packable operations per value against 2 transcendentals + 17 of the Abramowitz-Stegun erf form this replaces (the GEGLU epilogues
+    // are VALU-bound: profiles/r05_findings.md).  The fp32 (id-parity) mode keeps libm's erf.
     static __device__ __forceinline__ float gelu(float v) {
-        // erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), far below bf16 resolution
-        const float x = fabsf(v) * 0.70710678118654752440f;
-        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
-        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-        const float erf_abs = 1.f - poly * __expf(-x * x);
-        const float erfv = v < 0.f ? -erf_abs : erf_abs;
-        return 0.5f * v * (1.f + erfv);
+        const float a = fminf(fabsf(v), 4.5f);
+        const float t = a * 0.44444444444444444f - 1.f;
+        float p = 4.258678854e-02f;
+        p = p * t + -2.178250334e-02f;
+        p = p * t + -1.763804275e-01f;
+        p = p * t + 1.763150563e-01f;
+        p = p * t + 2.049072476e-01f;
+        p = p * t + -4.347814101e-01f;
+        p = p * t + 2.029682756e-01f;
+        p = p * t + 1.472158170e-01f;
+        p = p * t + -2.465923949e-01f;
+        p = p * t + 1.330395059e-01f;
+        p = p * t + -2.749713406e-02f;
+        return fmaxf(v, 0.f) + p;
     }
 };
 

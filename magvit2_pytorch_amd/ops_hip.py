@@ -75,6 +75,10 @@ _SIGS = {
     'mv2_pw_se_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     'mv2_pw_se': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.c_int, C.c_void_p]),
+    'mv2_ff_eligible': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    'mv2_ff_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    'mv2_ff_counter_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    'mv2_ff': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_lfq_train': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'mv2_lfq_stats_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     'mv2_lfq_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -272,6 +276,21 @@ class HipOps:
         fn = self.lib.mv2_pw_se
         args = (dt, _ptr(x), _ptr(wp), _ptr(bias), _ptr(se_wk), float(se_bk), _ptr(out), _ptr(se_part), rows, Pn, Cc)
         return _mk(fn, args, 'mv2_pw_se', (x, wp, bias, se_wk, out, se_part), [out, se_part])
+
+    def ff_eligible(self, dt, rows, Cc, hidden_pad) -> bool:
+        return bool(self.lib.mv2_ff_eligible(dt, rows, Cc, hidden_pad))
+
+    def ff_sizes(self, rows, Cc, hidden_pad):
+        """(slab workspace bytes, ticket-counter bytes) of mv2_ff for this shape on this device."""
+        with torch.cuda.device(self.device):
+            return int(self.lib.mv2_ff_workspace_bytes(rows, Cc, hidden_pad)), int(self.lib.mv2_ff_counter_bytes(rows, Cc, hidden_pad))
+
+    def ff(self, dt, x, w1, b1, w2, b2, out, rows, Cc, hidden_pad, shift_hw, T, ws, counters):
+        fn = self.lib.mv2_ff
+        nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+        args = (dt, _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), rows, Cc, hidden_pad, shift_hw, T,
+                _ptr(ws), nb(ws), _ptr(counters), nb(counters))
+        return _mk(fn, args, 'mv2_ff', (x, w1, b1, w2, b2, out, ws, counters), [out])
 
     def video_to_ndhwc(self, dt, video, out, B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems):
         fn, args = self.lib.mv2_video_to_ndhwc, (dt, _ptr(video), _ptr(out), B, Cc, T, H, W, pad_t, pad_hw, c_pad, tail_elems)

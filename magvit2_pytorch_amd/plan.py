@@ -35,6 +35,11 @@ class LoweringOptions:
     pw_se: bool = True             # mv2_pw_se (1x1x1 conv + ELU + pooling records) instead of mv2_conv + a pooling pass
     se_two_launch: bool = True     # small frames: mv2_se_pool_fc1 / mv2_se_fc2_apply instead of pool / gate / apply
     conv_rms: bool = True          # RMSNorm folded into the following GEMM (mv2_conv_rms)
+    fuse_ff: bool = True           # FeedForward (RMSNorm + ff1 + GEGLU + ff2 + residual) as one launch (mv2_ff) at C = 256 / 512
+    # ... from this many rows on.  Measured on MI355X (profiles/r05_findings.md, one launch against the two it replaces): 20480 rows at
+    # C = 256: 46 against 53 us, 5120 rows at C = 512: 39 / 44, 81920 rows: 125 / 200, 20480 rows at C = 512: 151 / 159, 5120 token-shifted
+    # rows: 43 / 51 - but 1280 token-shifted rows (20 row tiles for 256 CUs): 32 against 27.  0 forces the kernel (lockstep tests).
+    fuse_ff_min_rows: int = 2560
     conv_in: bool = True           # convin.hip instead of the generic gather kernel
     conv_out: bool = True          # convout.hip instead of the generic gather kernel
     convin_cpad: int = 4           # channels per input pixel of mv2_video_to_ndhwc (4: 8-byte bf16 pixels, 8: the round-1 layout)
@@ -124,6 +129,13 @@ class PackedModel:
             put(pre + '.ff1', pc)
             self.hidden_pad[pre] = hp
             put(pre + '.ff2', P.pack_pointwise(f(pre + '.net.2.weight').flatten(1), f(pre + '.net.2.bias'), dtype, k_pad=hp))
+            pc2 = self.convs[pre + '.ff2']
+            if (dtype == torch.bfloat16 and not cond and dim in (256, 512) and pc.seg_bytes == 128 and pc2.seg_bytes == 128 and pc2.co_pad == dim
+                    and pc.nsteps == dim // 64 and pc2.nsteps == hp // 64 and pc.bias is not None and pc2.bias is not None):
+                # mv2_ff's weight images: the same bytes in fragment order (a token-shifted first conv has the same K order: current-frame
+                # half, then previous-frame half)
+                self.frag[pre + '.ff1'] = P.to_frag_major(pc.wp)
+                self.frag[pre + '.ff2'] = P.to_frag_major(pc2.wp)
 
         def residual_unit_mod(pre):
             # ResidualUnitMod / Conv3DMod (reference M:680-753, 946-988): shared weights, per-sample input modulation and
@@ -581,7 +593,24 @@ class Plan:
         return out
 
     def _feed_forward(self, steps, pre, x: Act, shift: bool, cond=None) -> Act:
-        pm = self.pm
+        pm, ops = self.pm, self.ops
+        hp = pm.hidden_pad.get(pre, 0)
+        if (cond is None and OPTIONS.fuse_ff and x.rows >= OPTIONS.fuse_ff_min_rows and (pre + '.ff1') in pm.frag
+                and ops.ff_eligible(self.dt, x.rows, x.C, hp)):
+            # the whole block in one launch (ff.hip): the hidden tensor stays on chip
+            pc1, pc2 = pm.convs[pre + '.ff1'], pm.convs[pre + '.ff2']
+            out = Act(self.arena.get(x.rows * x.C, self.dtype), x.B, x.T, x.H, x.W, x.C)
+            wsb, cntb = ops.ff_sizes(x.rows, x.C, hp)
+            ws = self.arena.get((wsb + 3) // 4, torch.float32) if wsb > 0 else None
+            steps.append(ops.ff(self.dt, x.t, pm.frag[pre + '.ff1'], pc1.bias, pm.frag[pre + '.ff2'], pc2.bias, out.t, x.rows, x.C, hp,
+                                x.H * x.W if shift else 0, x.T, ws, self._tickets(cntb) if wsb > 0 else None))
+            steps[-1].label = pre + '.ff'
+            self.step_flops[id(steps[-1])] = 2.0 * x.rows * (pc1.co_real * pc1.k_real + pc2.co_real * pc2.k_real)
+            self.step_names.append(pre + '.ff')
+            if ws is not None:
+                self.arena.put(ws)
+            self.arena.put(x.t)
+            return out
         kw = dict(pt=1, check_bounds=True) if shift else dict(check_bounds=False)
         if cond is None:       # RMSNorm's row scale rides in the GEMM launch (mv2_conv_rms) where the kernel can
             h = self._conv(steps, pre + '.ff1', pm.convs[pre + '.ff1'], x, act=P.ACT_GEGLU, rms_shift=shift, **kw)

@@ -371,6 +371,34 @@ class CpuOps:
         step.what = 'rms_rowscale'
         return step
 
+    # ------------------------------------------------------------------ FeedForward in one launch (mv2_ff, csrc/ff.hip)
+    def ff_eligible(self, dt, rows, Cc, hidden_pad) -> bool:
+        return bool(dt == 0 and rows > 0 and Cc in (256, 512) and hidden_pad >= 64 and hidden_pad % 64 == 0 and hidden_pad <= 8192)
+
+    def ff_sizes(self, rows, Cc, hidden_pad):
+        return 0, 0
+
+    def ff(self, dt, x, w1, b1, w2, b2, out, rows, Cc, hidden_pad, shift_hw, T, ws, counters):
+        """out = round(W2 round(geglu((W1 xs) / |xs| + b1)) + b2 + x), xs = the (token-shifted) row; both weight images are fragment-major
+        (include/mv2.h mv2_ff); h is rounded to the storage dtype like the kernel's LDS panel, the output once."""
+        assert self.ff_eligible(dt, rows, Cc, hidden_pad)
+        def step(stream):
+            hp = hidden_pad
+            p1 = self._plain_from_frag_major(w1)                                     # [C / 64][co_pad][64]
+            W1 = p1.permute(1, 0, 2).reshape(p1.shape[1], -1)[: 2 * hp, :Cc].to(self.acc)
+            p2 = self._plain_from_frag_major(w2)                                     # [hp / 64][C][64]
+            W2 = p2.permute(1, 0, 2).reshape(p2.shape[1], -1)[:Cc, :hp].to(self.acc)
+            xs = self._shifted(x, rows, Cc, shift_hw, T)
+            rs = 1.0 / xs.norm(dim=1).clamp(min=1e-12)
+            D = (xs @ W1.t()) * rs[:, None] + b1[: 2 * hp].to(self.acc)
+            Dv = D.reshape(rows, hp // 32, 2, 32)                                    # packed blocks: 32 values | 32 gates
+            h = (torch.nn.functional.gelu(Dv[:, :, 1]) * Dv[:, :, 0]).reshape(rows, hp).to(x.dtype).to(self.acc)
+            y = (h @ W2.t() + b2[:Cc].to(self.acc)) + x[: rows * Cc].reshape(rows, Cc).to(self.acc)
+            out[: rows * Cc].copy_(y.reshape(-1).to(out.dtype))
+        step.outs = [out]
+        step.what = 'ff'
+        return step
+
     # ------------------------------------------------------------------ squeeze-excite
     def pw_se_rows(self, dt, rows, Pn, Cc) -> int:
         if dt != 0 or Cc not in (128, 256, 512) or rows % Pn:      # MV2_BF16 = 0

@@ -1129,3 +1129,44 @@ def test_bench_workloads_match_baseline_configs():
     assert kw4['use_fsq'] and kw4['fsq_levels'] == [8, 5, 5, 5]
     assert bench.workload(3)[0]['image_size'] == 256 and bench.workload(3)[0]['max_dim'] == 512
     assert bench.parse(['--config', '3']).config == 3
+
+
+def test_bf16_gelu_polynomial_matches_exact_gelu():
+    """csrc/common.h Act<BF16>::gelu = max(v, 0) + P(t), t = 2 min(|v|, 4.5) / 4.5 - 1: the coefficients in the header, evaluated in float32
+    Horner form as the kernel does, stay within 2e-5 of the exact erf-GELU (reference F.gelu, magvit2_pytorch.py:468) on [-12, 12]."""
+    import os, re
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'magvit2_pytorch_amd', 'csrc', 'common.h')).read()
+    body = src[src.index('template <> struct Act<BF16>'):]
+    body = body[body.index('static __device__ __forceinline__ float gelu'):body.index('return fmaxf(v, 0.f) + p;')]
+    lead = float(re.search(r'float p = ([-+0-9.e]+)f;', body).group(1))
+    rest = [float(x) for x in re.findall(r'p = p \* t \+ ([-+0-9.e]+)f;', body)]
+    assert len(rest) == 10 and '4.5f' in body and '0.44444444444444444f' in body
+    v = np.linspace(-12, 12, 480001).astype(np.float32)
+    a = np.minimum(np.abs(v), np.float32(4.5))
+    t = (a * np.float32(0.44444444444444444) - np.float32(1)).astype(np.float32)
+    p = np.full_like(v, np.float32(lead))
+    for c in rest:
+        p = (p * t + np.float32(c)).astype(np.float32)
+    g = np.maximum(v, np.float32(0)) + p
+    exact = torch.nn.functional.gelu(torch.from_numpy(v).double()).numpy()
+    assert np.abs(g - exact).max() <= 2e-5
+
+
+def test_fused_feed_forward_lowering_rule():
+    """plan.Plan._feed_forward takes mv2_ff (one launch) from LoweringOptions.fuse_ff_min_rows rows on, where the packed model carries the
+    fragment images (bf16, C = 256 / 512, unconditioned), and the two-launch form below it / with fuse_ff off; both lowerings agree on the
+    emulation."""
+    kw, cfg, sd, v = _full_width_case()
+    outs = {}
+    for key, opts in (('rule', {}), ('forced', dict(fuse_ff_min_rows=0)), ('off', dict(fuse_ff=False))):
+        with plan_mod.lowering_options(**opts):
+            tok = emulated_tokenizer(kw, sd, torch.bfloat16)
+            plan = tok._plan(1, 5)[0]
+            outs[key] = (list(plan.step_names), tok(v, return_codes=True, return_recon=True))
+    small_rows = all(not n.endswith('.ff') for n in outs['rule'][0])          # a tiny test clip stays below 2560 rows per layer
+    assert small_rows and sum(n.endswith('.ff') for n in outs['forced'][0]) == 6 and sum(n.endswith('.ff1') for n in outs['off'][0]) == 6
+    assert len(outs['forced'][0]) == len(outs['off'][0]) - 6
+    assert torch.equal(outs['forced'][1][0], outs['off'][1][0]) and (outs['forced'][1][1] - outs['off'][1][1]).abs().max().item() <= 2e-2
+    assert plan_mod.LoweringOptions().fuse_ff_min_rows == 2560

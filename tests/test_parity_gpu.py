@@ -187,6 +187,76 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     run_lockstep(cfg, sd, v, torch.bfloat16)
 
 
+def test_lockstep_fused_feed_forward(monkeypatch):
+    """mv2_ff (FeedForward as one launch, csrc/ff.hip) forced at every size (the product takes it from 2560 rows on): the README spec at
+    its real widths, so both kernel forms (C = 256: four waves, C = 512: eight waves), split row tiles and the token-shifted time-axis
+    layers run launch by launch against the emulation."""
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, fuse_ff_min_rows=0))
+    kw = dict(image_size=32, init_dim=64, max_dim=512, codebook_size=1024, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=11, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(12))
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    names = Plan(PackedModel(cfg, sd, torch.bfloat16, HipOps('cuda:0')), 2, 5, 32, 32).step_names
+    assert sum(n.endswith('.ff') for n in names) == 6 and not any(n.endswith('.ff1') for n in names)
+    run_lockstep(cfg, sd, v, torch.bfloat16)
+
+
+@pytest.mark.parametrize('C,rows,shift_hw,T', [(256, 1000, 0, 1), (512, 333, 0, 1), (512, 640, 64, 5), (256, 384, 32, 3), (512, 5120, 0, 1), (256, 20480, 0, 1)])
+def test_ff_kernel_vs_two_launches_and_emulation(C, rows, shift_hw, T):
+    """mv2_ff against the pair of launches it replaces (mv2_conv_rms with the GEGLU epilogue + mv2_conv with the residual) on the same
+    packed weights: same MFMA order, h rounded once, output rounded once, so only 1-ulp bf16 flips from the RMS scale's summation order
+    (and, for split tiles, the order of the partial sums) may differ; ragged row counts, token shift, split tiles (tickets left zero,
+    run-to-run identical); the small shapes also against the CPU emulation of include/mv2.h's contract."""
+    from magvit2_pytorch_amd import pack as P
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops = HipOps('cuda:0')
+    dev, BF, DT = ops.device, torch.bfloat16, P.MV2_BF16
+    g = torch.Generator().manual_seed(C + rows)
+    inner = int(C * 4 * 2 / 3)
+    w1, b1 = torch.randn(2 * inner, C, generator=g) * C ** -0.5, torch.randn(2 * inner, generator=g) * 0.1
+    w2, b2 = torch.randn(C, inner, generator=g) * inner ** -0.5, torch.randn(C, generator=g) * 0.1
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)) * C ** 0.5
+    pc1, hp = P.pack_geglu_in(w1, b1, BF, in_scale=gamma, token_shift=shift_hw > 0)
+    pc2 = P.pack_pointwise(w2, b2, BF, k_pad=hp)
+    pc1.to(dev); pc2.to(dev)
+    f1, f2 = P.to_frag_major(pc1.wp), P.to_frag_major(pc2.wp)
+    x = (torch.randn(rows, C, generator=g) * 1.3).to(BF).to(dev).reshape(-1)
+    geo = dict(B=rows // shift_hw // T, Ti=T, Hi=1, Wi=shift_hw, To=T, Ho=1, Wo=shift_hw) if shift_hw else dict(B=1, Ti=1, Hi=1, Wi=rows, To=1, Ho=1, Wo=rows)
+
+    def desc(pc, Ci, act, out_c, pt, check):
+        return dict(dtype=DT, **geo, Ci=Ci, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1, pt=pt, ph=0, pw=0, kt=pc.kt, kh=pc.kh, kw=pc.kw,
+                    nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=check, act=act, store=P.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0,
+                    out_c=out_c, splitk=0)
+    d1, d2 = desc(pc1, C, P.ACT_GEGLU, pc1.co // 2, int(shift_hw > 0), int(shift_hw > 0)), desc(pc2, hp, P.ACT_NONE, pc2.co, 0, 0)
+    h = torch.empty(rows * hp, dtype=BF, device=dev)
+    ref = torch.empty(rows * C, dtype=BF, device=dev)
+    rs = torch.empty(rows, dtype=torch.float32, device=dev)
+    mk = lambda nbytes: torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev) if nbytes else None
+    st = ops.current_stream()
+    ops.rms_rowscale(DT, x, rs, rows, C, shift_hw, T)(st)
+    ops.conv(d1, x, x.numel() * 2, pc1.wp, pc1.segs_tensor(geo['Hi'], geo['Wi'], C, dev), pc1.bias, rs, None, h, mk(ops.conv_workspace_bytes(d1)))(st)
+    ops.conv(d2, h, h.numel() * 2, pc2.wp, pc2.segs_tensor(geo['Hi'], geo['Wi'], hp, dev), pc2.bias, None, x, ref, mk(ops.conv_workspace_bytes(d2)))(st)
+    assert ops.ff_eligible(DT, rows, C, hp)
+    wsb, cntb = ops.ff_sizes(rows, C, hp)
+    ws = mk(wsb)
+    cnt = torch.zeros(max(1, cntb // 4), dtype=torch.int32, device=dev) if wsb else None
+    outs = [torch.full((rows * C,), float('nan'), dtype=BF, device=dev) for _ in range(2)]
+    for o in outs:
+        ops.ff(DT, x, f1, pc1.bias, f2, pc2.bias, o, rows, C, hp, shift_hw, T, ws, cnt)(st)
+    ops.synchronize()
+    a, b = outs[0].float(), ref.float()
+    assert torch.isfinite(a).all() and torch.equal(outs[0], outs[1])
+    assert cnt is None or int(cnt.abs().sum()) == 0, 'a launch must leave its ticket words zero'
+    err = (a - b).abs()
+    assert (err <= 2 ** -6 * b.abs() + 4e-3).all() and (err > 0).float().mean().item() <= 0.02, (err.max().item(), (err > 0).float().mean().item())
+    if rows <= 2048:
+        oc = torch.empty(rows * C, dtype=BF)
+        CpuOps().ff(DT, x.cpu(), f1.cpu(), pc1.bias.cpu(), f2.cpu(), pc2.bias.cpu(), oc, rows, C, hp, shift_hw, T, None, None)(0)
+        e2 = (outs[0].cpu().float() - oc.float()).abs()
+        assert (e2 <= 2 ** -6 * oc.float().abs() + 4e-3).all(), e2.max().item()
+
+
 def test_lockstep_conv_in_8byte_pixels(monkeypatch):
     """conv_in with 4-channel bf16 pixels (8-byte aligned 16-byte gathers): probes the cheaper layout."""
     monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, convin_cpad=4))
