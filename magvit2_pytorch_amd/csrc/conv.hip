@@ -344,15 +344,19 @@ MV2_WAITVM(0) MV2_WAITVM(8)
 #undef MV2_WAITVM
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// workgroups per CU the dispatch rule counts on (LDS: 2 stages x (BCO + BPOS) x 128 B): 128 x 128 -> 2, 128 x 64 / 64 x 128 -> 3, 64 x 64 -> 5;
+// the register budget follows (nothing tied the two together)
+template <int BCO, int BPOS> struct PwDmaOcc { static constexpr int kWgs = BCO + BPOS >= 256 ? 2 : (BCO + BPOS >= 192 ? 3 : 5); };
+
 template <int BCO, int BPOS, int WCO, int WPOS, int NS, bool RMS>
-__global__ __launch_bounds__(256, 2) void conv_pw_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (PwDmaOcc<BCO, BPOS>::kWgs)) void conv_pw_dma_kernel(const ConvParams p) {
     typedef BF16 E;
     constexpr int NWPOS = BPOS / (32 * WPOS);
     static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
     constexpr int STAGE = (BCO + BPOS) * 128;
     constexpr int LPW = BCO / 32;                                // DMA loads per thread and step that fetch weight rows ...
     constexpr int LPS = (BCO + BPOS) / 32;                       // ... and in total (128 x 128: 4 weight + 4 activation)
-    static_assert(NS == 2 || (NS == 3 && LPS == 8), "vmcnt immediates below");      // the library launches NS = 2 (launch_dtype)
+    static_assert(NS == 2, "two stages: the vmcnt immediates below and the launcher (launch_pw_dma) know no other depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const mv2_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;

@@ -464,10 +464,11 @@ def test_larger_batch_full_size_properties():
     assert (g.sample(r[:1].cpu()) - g.recon_sample).abs().mean().item() <= BF16_GATES['cfg2_video128x17'][1]
 
 
-@pytest.mark.parametrize('C,frames,P', [(128, 20, 4096), (128, 3, 96), (256, 20, 1024), (256, 2, 64), (512, 20, 256), (512, 5, 256), (512, 36, 1024)])
+@pytest.mark.parametrize('C,frames,P', [(128, 20, 4096), (128, 3, 96), (256, 20, 1024), (256, 2, 64), (256, 40, 1024), (512, 20, 256), (512, 5, 256), (512, 36, 1024)])
 def test_pw_se_kernel_vs_emulation(C, frames, P):
     """mv2_pw_se (1x1x1 conv + ELU + SqueezeExcite pooling records, pwse.hip) against the CPU emulation: output rows within one
-    bf16 ulp of the fp32-accumulated value, records (max logit, sum exp, weighted sums) to 2e-3 relative; both row-tile sizes."""
+    bf16 ulp of the fp32-accumulated value, records (max logit, sum exp, weighted sums) to 2e-3 relative; both row-tile sizes and both wave
+    counts (C / 32 waves at C = 512 up to 8192 rows and at C = 256 on 64-row tiles - (256, 40, 1024) -, four waves elsewhere)."""
     from magvit2_pytorch_amd import pack as PK
     from magvit2_pytorch_amd.ops_hip import HipOps
     ops, cpu = HipOps('cuda:0'), CpuOps()
