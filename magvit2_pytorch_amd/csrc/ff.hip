@@ -465,10 +465,6 @@ extern "C" int mv2_ff(int dtype, const void* x, const void* w1, const float* b1,
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ff_prof), &prof_buf, sizeof(prof_buf));
     }
 #endif
-    int depth = 4;
-#ifdef MV2_EXPERIMENTS
-    if (const char* e = getenv("MV2_FF_D")) depth = atoi(e);
-#endif
 #define FF_LAUNCH(CTv, NWv, Dv, Av)                                                                                              \
     do {                                                                                                                         \
         if (hipFuncSetAttribute((const void*)ff_kernel<CTv, NWv, Dv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) != hipSuccess) \
@@ -494,7 +490,6 @@ extern "C" int mv2_ff(int dtype, const void* x, const void* w1, const float* b1,
 #endif
         FF_LAUNCH(2, 4, 4, 0);
     } else FF_LAUNCH(4, 8, 4, 0);
-    (void)depth;
 #undef FF_LAUNCH
     MV2_LAUNCH_CHECK();
 #ifdef MV2_EXPERIMENTS

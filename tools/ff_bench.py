@@ -1,7 +1,8 @@
 """Harness of mv2_ff (csrc/ff.hip: FeedForward as one launch) on the GPU box: every shape against the two-launch form it replaces
 (mv2_conv_rms with the GEGLU epilogue + mv2_conv with the residual: the validated path) element by element, small shapes also against the
 CPU emulation of the kernel semantics (oracle/ndhwc_ops.py), then HIP-event timings of both forms.
-usage: python tools/ff_bench.py [exp] [quick]      exp: load libmv2_hip_exp.so (MV2_FF_S / MV2_FF_D are read by that library)"""
+usage: python tools/ff_bench.py [exp] [quick | sweep [prof]]      exp: load libmv2_hip_exp.so (its knobs: MV2_FF_S parts per row tile, MV2_FF_ROT chunk
+rotation, MV2_FF_NW=8 the eight-wave C = 256 form, MV2_FF_ABL compile-time ablations 1 / 2 / 3 / 7 / 8 / 11 / 15, MV2_FF_PROF phase clocks)"""
 import os
 import sys
 
@@ -134,7 +135,7 @@ def sweep():
                 dict(MV2_FF_ABL='15', MV2_FF_S='1')]
     knobs = ('MV2_FF_ROT', 'MV2_FF_D', 'MV2_FF_S', 'MV2_FF_ABL', 'MV2_FF_PROF', 'MV2_FF_NW')
     if 'prof' in sys.argv[1:]:      # phase clocks of the kernel (the library prints one line per launch: the last one of a case is warm)
-        settings = [dict(MV2_FF_PROF='1'), dict(MV2_FF_PROF='1', MV2_FF_S='1'), dict(MV2_FF_PROF='1', MV2_FF_S='1', MV2_FF_D='8'),
+        settings = [dict(MV2_FF_PROF='1'), dict(MV2_FF_PROF='1', MV2_FF_S='1'), 
                     dict(MV2_FF_PROF='1', MV2_FF_ABL='2', MV2_FF_S='1'), dict(MV2_FF_PROF='1', MV2_FF_ABL='3', MV2_FF_S='1')]
     for name, C, rows, sh, T in shapes:
         for st in settings:
