@@ -4,7 +4,7 @@
 # usage: tools/check_spills.sh [file.hip ...]        (default: the product sources)
 cd "$(dirname "$0")/../magvit2_pytorch_amd/csrc" || exit 1
 T=$(mktemp -d)
-for f in ${@:-conv3p.hip conv3.hip convin.hip convout.hip pwse.hip conv.hip misc.hip attn.hip quant.hip}; do
+for f in ${@:-conv3p.hip conv3.hip convin.hip convout.hip pwse.hip ff.hip conv.hip misc.hip attn.hip quant.hip}; do
   b=$(basename "$f" .hip)
   hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -I../../include "$b.hip" -o "$T/$b.s" 2>/dev/null || { echo "$b: compile failed"; continue; }
   grep "\.name: \+_Z\|private_segment_fixed_size\|\.vgpr_count\|vgpr_spill" "$T/$b.s" |
