@@ -96,6 +96,21 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     assert lib.mv2_lfq(0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, 1, 64, 17, 2, 10.0, 1.0, None) == EINVAL   # 34 code dims > 32
     assert lib.mv2_fsq_codes(0, None, None, None, None, None, None, None, 1, 64, 4, 1, None) == EINVAL
     assert lib.mv2_taylor_kv(0, ptr, ptr, 1, 4, 16, 8, None) == EINVAL                          # more chunks than tokens
+    # mv2_ff: null pointers, widths other than 256 / 512, fp32, a hidden width that is not whole 64-unit blocks, in-place, a token shift whose
+    # frames do not tile the rows; the sizing queries are pure host functions (64 KB / 128 KB of fp32 slab per split row tile, one ticket word per tile)
+    assert lib.mv2_ff(0, None, ptr, ptr, ptr, ptr, ptr, 128, 256, 704, 0, 1, None, 0, None, 0, None) == EINVAL
+    buf2 = ctypes.create_string_buffer(4096); ptr2 = ctypes.cast(buf2, ctypes.c_void_p)
+    for args in ((0, 128, 384, 704, 0, 1), (1, 128, 256, 704, 0, 1), (0, 128, 256, 700, 0, 1), (0, 0, 256, 704, 0, 1), (0, 1280, 512, 1408, 256, 3)):
+        dt, rows, Cc, hp, sh, Tt = args
+        assert lib.mv2_ff(dt, ptr, ptr, ptr, ptr, ptr, ptr2, rows, Cc, hp, sh, Tt, None, 0, None, 0, None) == EINVAL, args
+        if sh == 0:
+            assert lib.mv2_ff_eligible(dt, rows, Cc, hp) == 0, args
+    assert lib.mv2_ff(0, ptr, ptr, ptr, ptr, ptr, ptr, 128, 256, 704, 0, 1, None, 0, None, 0, None) == EINVAL          # x == out
+    assert lib.mv2_ff_eligible(0, 20480, 256, 704) == 1 and lib.mv2_ff_eligible(0, 5120, 512, 1408) == 1
+    assert lib.mv2_ff_workspace_bytes(20480, 256, 704) == 0                                        # 320 row tiles: whole tiles, no slabs
+    assert lib.mv2_ff_workspace_bytes(5120, 512, 1408) == 80 * 3 * 128 * 1024                      # 80 tiles in three parts (256 CUs assumed without a device)
+    assert lib.mv2_ff_counter_bytes(5120, 512, 1408) == 80 * 4
+    assert lib.mv2_ff(0, ptr, ptr, ptr, ptr, ptr, ptr2, 5120, 512, 1408, 0, 1, None, 0, None, 0, None) == -3            # MV2_EWORKSPACE: split tiles need slabs + tickets
 
 
 def test_launch_rules_of_the_library_match_their_restatement():
