@@ -34,6 +34,8 @@ Extra objects on the JSON line:
   configs3       — (N = 1, configs[1]) BASELINE configs[3] timed in the same process (>= 5 steps): ms/step, frames/s, conv3 fraction and the
                    roofline of the MFMA attention kernel at 1024 + 4 keys (QK^T + PV flops / event time / 2.5 PF).
   configs4_fsq   — (N = 1, configs[1]) BASELINE configs[4]'s per-GPU shape, tokenize() only.
+  two_streams    — (N = 1, configs[1]) NOT the headline: two independent forward() calls in flight on two HIP streams (two tokenizer instances):
+                   what a server that overlaps requests gets out of the latency-bound single-clip step.
   exact_fp32_mode— (N = 1, configs[1]) throughput and id mismatch of the bit-exact mode (fp32 storage + fp32 MFMA).
   cpu_baseline   — kind "reference": the reference's own VideoTokenizer.forward (build-time copy oracle/_ref, loaded by oracle/ref_loader.py)
                    timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only); kind "port"
@@ -459,6 +461,35 @@ def _main(args, lowering):
         except Exception as e:
             configs4 = dict(error=repr(e)[:300])
 
+    # ---- two independent clips in flight (NOT the headline; a serving figure): at 1 clip per step the chip is latency-bound - 130 dependent
+    # launches of ~20 us - so a second tokenizer instance on a second HIP stream fills the gaps.  Each stream runs the SAME captured graph of
+    # the same workload on its own plan buffers; a "step" here is two forward() calls, one per stream, both counted.
+    two_streams = None
+    if extra_legs and not args.no_batch4 and not args.no_graph:
+        try:
+            from magvit2_pytorch_amd.streaming import ClipLanes
+            lanes = ClipLanes(tok, lanes=2)                              # the product's utility: a replica of `tok` on a second stream
+            vb = torch.randn(B, 3, T, size, size, generator=torch.Generator().manual_seed(2)).to(dev)
+
+            def pair():
+                return tuple(lanes.map((video, vb), return_codes=True, return_recon=True))
+            for _ in range(6):                                           # eager run, graph capture and first replays on each lane
+                pair()
+            sync()
+            n2 = max(20, min(args.steps, 100))
+            e2, (ra, rb) = timed(pair, n2, sync)
+            ref_codes, _ = tok(video, return_codes=True, return_recon=True)      # the same clip through the single-stream path: same ids
+            sync()
+            two_streams = dict(what='two forward() calls in flight on two HIP streams (magvit2_pytorch_amd.streaming.ClipLanes: two tokenizer replicas, same weights, one clip each): a serving '
+                                    'figure, not the headline - value counts one call per step', pairs=n2, ms_per_pair=round(e2 * 1e3, 4),
+                               frames_per_s=round(2 * B * T / e2, 1), speedup_vs_headline=round(2 * B * T / e2 / value, 3),
+                               ids_equal_single_stream=bool(torch.equal(ra[0], ref_codes)), finite=bool(torch.isfinite(ra[1]).all() and torch.isfinite(rb[1]).all()))
+            del lanes, vb
+            torch.cuda.empty_cache()
+            log(f'two-streams leg: {two_streams["ms_per_pair"]} ms per pair -> {two_streams["frames_per_s"]} frames/s')
+        except Exception as e:
+            two_streams = dict(error=repr(e)[:300])
+
     # ---- the bit-exact mode on the same workload (driver-visible): fp32 storage + fp32 MFMA
     exact = None
     if extra_legs and not args.no_exact:
@@ -485,7 +516,7 @@ def _main(args, lowering):
         config=dict(workload=f'{what}; ({B},3,{T},{size},{size}) clip(s) per GPU, README layer spec, random-init weights seed 0',
                     global_batch=B * world, frames_per_clip=T, parallelism=f'dp{world} (clip sharding, no data-path collective)',
                     hip_graph=not args.no_graph),
-        roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+        roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, two_streams=two_streams, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
     if lowering:
         out['lowering_overrides'] = lowering       # A/B run: NOT the product's lowering
     if emu:

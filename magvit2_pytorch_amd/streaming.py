@@ -78,3 +78,75 @@ def tokenize_stream(tokenizer, clips: Iterable[torch.Tensor], depth: int = 2, co
         h, g = done.popleft()
         g.synchronize()
         yield h
+
+
+class ClipLanes:
+    """Several independent calls in flight: `lanes` replicas of an eval tokenizer (same weights, own plan buffers and HIP graphs), one HIP
+    stream each, clips dealt round-robin.
+
+    Why: at one clip per call the path is a chain of ~130 dependent launches of ~20 us each and the chip idles through their latency
+    phases (profiles/r05_findings.md section 5); a second, independent chain on a second stream fills them: measured on MI355X,
+    configs[1], two lanes: 3.91 ms per pair of clips against 2 x 2.64 ms (1.35 x the frames/s; `bench.py`'s `two_streams` object).  Batching
+    the clips into one call (`forward` on a (B, ...) tensor) is still better where the caller HAS the clips together (4 clips: 1.79 ms
+    per clip); lanes are for requests that arrive one by one.  Results are those of the plain calls (same kernels, same plans).
+
+    Stream semantics: a lane's stream waits for the caller's current stream before each call (the clip may have been produced there), and
+    `map` makes the caller's stream wait for a result's event before yielding it, so consumers stay stream-ordered.  On a CPU backend
+    (tests: the kernel emulation) it degrades to the plain loop.  The reference has no equivalent."""
+
+    def __init__(self, tokenizer, lanes: int = 2):
+        assert lanes >= 1
+        tokenizer.eval()
+        self.device = tokenizer.device
+        self.on_gpu = self.device.type == 'cuda'
+        self.toks = [tokenizer]
+        for _ in range(lanes - 1):
+            dup = tokenizer.copy_for_eval()
+            dup.compute_dtype, dup.use_hip_graph = tokenizer.compute_dtype, tokenizer.use_hip_graph
+            if not self.on_gpu and getattr(tokenizer, '_ops', None) is not None:
+                dup._set_backend(tokenizer._ops)                      # test hook: the injected emulation backend serves every lane
+            self.toks.append(dup)
+        self.streams = [torch.cuda.Stream(self.device) for _ in self.toks] if self.on_gpu else [None] * lanes
+
+    @staticmethod
+    def _tensors(out):
+        if torch.is_tensor(out):
+            yield out
+        elif isinstance(out, (tuple, list)):
+            for o in out:
+                yield from ClipLanes._tensors(o)
+
+    @torch.no_grad()
+    def map(self, clips: Iterable[torch.Tensor], method: str = 'forward', **kw) -> Iterator:
+        """yields `getattr(tokenizer, method)(clip, **kw)` for every clip, in order, with up to `lanes` calls in flight"""
+        n = len(self.toks)
+        pending = deque()
+
+        def finish():
+            out, ev = pending.popleft()
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for t in self._tensors(out):
+                    t.record_stream(cur)                              # allocated on the lane's stream, consumed on the caller's
+            return out
+
+        for i, v in enumerate(clips):
+            tok = self.toks[i % n]
+            fn = tok if method == 'forward' else getattr(tok, method)
+            if not self.on_gpu:
+                pending.append((fn(v, **kw), None))
+            else:
+                s = self.streams[i % n]
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    out = fn(v, **kw)
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(s)
+                pending.append((out, ev))
+            if len(pending) >= n:
+                yield finish()
+        while pending:
+            yield finish()

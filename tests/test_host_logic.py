@@ -1185,3 +1185,22 @@ def test_fused_feed_forward_lowering_rule():
     assert len(outs['forced'][0]) == len(outs['off'][0]) - 6
     assert torch.equal(outs['forced'][1][0], outs['off'][1][0]) and (outs['forced'][1][1] - outs['off'][1][1]).abs().max().item() <= 2e-2
     assert plan_mod.LoweringOptions().fuse_ff_min_rows == 2560
+
+
+def test_clip_lanes_match_plain_calls_on_the_emulation():
+    """streaming.ClipLanes (replicas of the tokenizer on their own HIP streams; on the CPU emulation a plain loop over the replicas) yields, in
+    order, what the plain calls give - forward() tuples and tokenize() ids - for more clips than lanes and for an empty list."""
+    from magvit2_pytorch_amd.streaming import ClipLanes
+    kw = dict(image_size=16, init_dim=8, max_dim=32, codebook_size=64, layers=README_LAYERS)
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=3, randomize_se=True)
+    tok = emulated_tokenizer(kw, sd, torch.float32)
+    clips = [torch.randn(1, 3, 5, 16, 16, generator=torch.Generator().manual_seed(20 + i)) for i in range(5)]
+    lanes = ClipLanes(tok, lanes=2)
+    assert len(lanes.toks) == 2 and lanes.toks[1] is not tok
+    want = [tok(v, return_codes=True, return_recon=True) for v in clips]
+    got = list(lanes.map(clips, return_codes=True, return_recon=True))
+    assert len(got) == 5 and all(torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) for g, w in zip(got, want))
+    ids = list(lanes.map(clips[:3], method='tokenize'))
+    assert all(torch.equal(i, w[0]) for i, w in zip(ids, want))
+    assert list(lanes.map([])) == []
