@@ -87,6 +87,7 @@ def parse(argv=None):
     ap.add_argument('--no-exact', action='store_true', help='skip the exact-fp32-mode leg')
     ap.add_argument('--no-soak', action='store_true')
     ap.add_argument('--no-batch4', action='store_true', help='skip the configs[2] per-GPU-shape leg of the N = 1 line')
+    ap.add_argument('--no-two-streams', action='store_true', help='skip the two-calls-in-flight (streaming.ClipLanes) leg of the N = 1 line')
     ap.add_argument('--no-configs34', action='store_true', help='skip the configs[3] / configs[4] legs of the N = 1 line')
     ap.add_argument('--breakdown', default='', help='write the per-launch timing table to this json file')
     ap.add_argument('--lowering', default='', help='A/B only: comma-separated fields of plan.LoweringOptions, e.g. fuse_ff=0,fuse_ff_min_rows=0 '
@@ -465,7 +466,7 @@ def _main(args, lowering):
     # launches of ~20 us - so a second tokenizer instance on a second HIP stream fills the gaps.  Each stream runs the SAME captured graph of
     # the same workload on its own plan buffers; a "step" here is two forward() calls, one per stream, both counted.
     two_streams = None
-    if extra_legs and not args.no_batch4 and not args.no_graph:
+    if extra_legs and not args.no_two_streams and not args.no_graph:
         try:
             from magvit2_pytorch_amd.streaming import ClipLanes
             lanes = ClipLanes(tok, lanes=2)                              # the product's utility: a replica of `tok` on a second stream

@@ -8,7 +8,7 @@ L=$O/${TAG}_ab_${VAR}.log; : > $L
 for pass in $(seq 1 $PASSES); do
   for v in $VALS; do
     echo "#### pass $pass $VAR=$v $*" >> $L
-    (env $VAR="$v" timeout 240 python tools/bench_exp.py --steps 200 --warmup 10 --no-cpu-baseline --no-exact --no-batch4 --no-configs34 --no-soak "$@" 2>&1 | tail -1 | cut -c1-230) >> $L 2>&1
+    (env $VAR="$v" timeout 240 python tools/bench_exp.py --steps 200 --warmup 10 --no-cpu-baseline --no-exact --no-batch4 --no-two-streams --no-configs34 --no-soak "$@" 2>&1 | tail -1 | cut -c1-230) >> $L 2>&1
   done
 done
 grep -o "####.*\|ms_per_step\": [0-9.]*" $L | paste - -

@@ -7,7 +7,7 @@ L=$O/${TAG}_ab_lowering.log; : > $L
 for pass in $(seq 1 $PASSES); do
   for opt in "$A" "$B"; do
     echo "#### pass $pass lowering='$opt' $*" >> $L
-    (timeout 240 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-exact --no-configs34 ${opt:+--lowering $opt} "$@" 2>&1 | tail -1 | python -c "
+    (timeout 240 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-exact --no-two-streams --no-configs34 ${opt:+--lowering $opt} "$@" 2>&1 | tail -1 | python -c "
 import sys, json
 for l in sys.stdin:
     try:

@@ -10,7 +10,7 @@ cd $R
 (timeout 600 python bench.py --breakdown $O/${TAG}_per_launch_events_b1.json 2>&1 | tail -16) > $O/${TAG}_bench_b1.log 2>&1
 (timeout 300 python bench.py --config 2 --steps 100 --no-cpu-baseline --no-exact --breakdown $O/${TAG}_per_launch_events_b4.json 2>&1 | tail -3) > $O/${TAG}_bench_b4.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact --no-batch4 --no-configs34 --no-graph --no-soak"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact --no-batch4 --no-two-streams --no-configs34 --no-graph --no-soak"
 stats() {   # stats <suffix> <bench args...>: rocprofv3 --kernel-trace --stats of one bench command, summary csv copied beside the logs
   local sfx=$1; shift
   (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_$sfx -- $BENCH "$@" > $O/${TAG}_rocprof_$sfx.log 2>&1)
