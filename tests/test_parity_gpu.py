@@ -574,6 +574,50 @@ def test_pointwise_dma_kernel_vs_emulation(case):
     assert (a != b).float().mean().item() < 0.03
 
 
+@pytest.mark.parametrize('T,H,W,Ci,Cq,shuffle,act', [(5, 32, 32, 128, 64, (1, 2, 2), 'silu'), (17, 32, 32, 128, 128, (1, 2, 2), 'silu'), (5, 29, 29, 256, 256, (2, 1, 1), 'silu'),
+                                                     (4, 33, 31, 512, 256, (1, 2, 2), 'silu'), (20, 16, 16, 256, 128, (1, 2, 2), 'none'), (3, 16, 16, 128, 64, (1, 2, 2), 'silu')])
+def test_upsample_launches_vs_emulation_and_frame_by_frame(T, H, W, Ci, Cq, shuffle, act):
+    """The up-sampling convolutions (1x1x1 conv + SiLU + depth-to-space / depth-to-time store behind mv2_conv) at 256 / 512 / 1024 packed
+    columns, ragged row counts, both shuffles: against the CPU emulation, and bit for bit against the same clip pushed through frame by
+    frame (other tile rules of the library: every output element accumulates its k-steps in the same order whatever the tile).  Written for
+    a row-streaming kernel that was measured slower and not kept (tools/experiments/up_row_streaming.hip); the cases stay."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(T * 1000 + Ci + Cq)
+    rt, rh, rw = shuffle
+    Q = rt * rh * rw
+    w2d = torch.randn(Q * Cq, Ci, generator=g) / Ci ** 0.5
+    bias = torch.randn(Q * Cq, generator=g) * 0.1
+    pc = PK.pack_shuffle_up(w2d, bias, torch.bfloat16, Q)
+    dev = ops.device
+    wg, bg = pc.wp.to(dev), pc.bias.to(dev)
+    ACT = PK.ACT_SILU if act == 'silu' else PK.ACT_NONE
+
+    def run(Tn, x):
+        d = dict(dtype=PK.MV2_BF16, B=1, Ti=Tn, Hi=H, Wi=W, Ci=Ci, To=Tn, Ho=H, Wo=W, co=pc.co, co_pad=pc.co_pad, st=1, sh=1, sw=1, pt=0, ph=0, pw=0,
+                 kt=1, kh=1, kw=1, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=0, act=ACT, store=PK.STORE_SHUFFLE, rt=rt, rh=rh, rw=rw,
+                 crop_t=0, out_c=Cq, splitk=0)
+        n_out = Tn * H * W * Q * Cq
+        og = torch.full((n_out,), float('nan'), dtype=torch.bfloat16, device=dev)
+        ops.conv(d, x.to(dev), x.numel() * 2, wg, pc.segs_tensor(H, W, Ci, dev), bg, None, None, og, None)(ops.current_stream())
+        ops.synchronize()
+        return d, og.cpu()
+    M = T * H * W
+    x = torch.randn(M * Ci, generator=g).to(torch.bfloat16)
+    d, out = run(T, x)
+    oc = torch.full((out.numel(),), float('nan'), dtype=torch.bfloat16)
+    cpu.conv(d, x, x.numel() * 2, pc.wp, pc.segs_tensor(H, W, Ci, 'cpu'), pc.bias, None, None, oc, None)(None)
+    a, b = out.float(), oc.float()
+    assert torch.isfinite(a).all() and ((a - b).abs() <= 2 ** -7 * b.abs() + 4e-3).all(), (a - b).abs().max().item()
+    if M >= 4096 and T > 1:
+        # frame by frame the same launch is below the row threshold and runs on the tiled kernels: depth-to-space keeps frames apart
+        # (depth-to-time interleaves the two output frames of an input frame: frame t -> output frames rt t, rt t + 1)
+        per = H * W * Ci
+        pieces = [run(1, x[t * per:(t + 1) * per])[1] for t in range(T)]
+        assert torch.equal(torch.cat(pieces), out), 'streaming and tiled kernels must agree bit for bit'
+
+
 @pytest.mark.parametrize('B,T,H,W,ci,kt', [(1, 20, 128, 128, 3, 7), (2, 3, 20, 36, 3, 7), (1, 2, 9, 50, 4, 7), (3, 1, 16, 32, 1, 1), (1, 5, 8, 32, 3, 3)])
 def test_conv_in_kernel_vs_emulation(B, T, H, W, ci, kt):
     """mv2_conv_in (convin.hip: halo frames of an 8 x 32 tile staged once, weight slice per time tap in LDS) against the dense
