@@ -995,7 +995,11 @@ extern "C" size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d) {
 
 extern "C" size_t mv2_conv3_counter_bytes(const mv2_conv_desc* d) {
     if (!d || !eligible3(*d)) return 0;
-    return (size_t)plan3(*d).n_tiles * sizeof(uint32_t);
+    size_t extra = 0;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_CONV3_EXTRA_COUNTERS")) extra = (size_t)atoi(e);      // tools/experiments/conv3p_persistent.hip keeps its queue words behind the tickets
+#endif
+    return ((size_t)plan3(*d).n_tiles + extra) * sizeof(uint32_t);
 }
 
 extern "C" int mv2_conv3_tiles(const mv2_conv_desc* d, int* tile_h, int* tile_w) {

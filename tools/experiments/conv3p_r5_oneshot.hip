@@ -42,11 +42,25 @@ constexpr int ROWP = 144;                                             // LDS pit
 constexpr int NPIECE = (HR * ROWP + 1023) / 1024;                     // 1 KB DMA pieces per halo image (26)
 constexpr int IMG = NPIECE * 1024;
 constexpr int PPW = (NPIECE + 3) / 4;                                 // pieces per wave (7; waves 2, 3 repeat pieces 24, 25)
-constexpr int RING = 6;                                               // weight fragments in flight per wave (6 = 3 taps; must divide the 18 fragments of a group)
+#ifndef MV2_C3P_RING
+#define MV2_C3P_RING 6
+#endif
+constexpr int RING = MV2_C3P_RING;                                    // weight fragments in flight per wave (6 = 3 taps; must divide the 18 fragments of a group)
 static_assert(18 % RING == 0, "ring slots must divide the 18 fragments of a group");
-// The ablation / scheduling knobs this kernel was tuned with (ring depth, burst vs interleaved fragment reads, priorities, the timing-only
-// ablations, frames-inside-tiles block order, occupancy override) live with their measurements: tools/experiments/conv3p_r5_oneshot.hip
-// (the same kernel with the knobs, built by tools/build_c3p_r5.sh), profiles/r04_findings.md sections 2-3.  The product source has one path.
+#ifndef MV2_C3P_ILV
+#define MV2_C3P_ILV 1
+#endif
+#ifndef MV2_C3P_PRIO
+#define MV2_C3P_PRIO 0
+#endif
+// ABL (experiments, TIMING ONLY - results are wrong): 1 = the next group's halo is never requested (no DMA issue in the tap loop),
+// 2 = 1 + no group barrier, 3 = 2 + no weight reloads, 4 = 3 + no fragment reads (bare MFMA stream).  What a wave ALONE on its SIMD loses where.
+#ifndef MV2_C3P_ABL
+#define MV2_C3P_ABL 0
+#endif
+#ifndef MV2_C3P_WDEAD
+#define MV2_C3P_WDEAD 1
+#endif
 constexpr int SLAB = BCO * BPOS * 4;
 constexpr int XCH = 4 * 8192;                                         // exchange region: [wave][2 tiles][4][64 lanes][16 B]
 static_assert(NPIECE == 26 && PPW == 7, "piece bookkeeping below");
@@ -90,6 +104,7 @@ inline FastDiv make_fastdiv(uint32_t d) {
 struct P3Params {
     FastDiv per_co, S, tiles_sp, T, tiles_w;
     uint32_t grid;                        // = gridDim.x (the hidden kernel argument sits in another cache line)
+    int32_t time_inner;                   // block order inside a (channel tile, clip): 1 = frames inside spatial tiles, 0 = spatial tiles inside frames
     int32_t nA, tilesA, SB, tiles_per_xcd; // two-class work list (nA = 0: uniform): per XCD nA class-A blocks = tilesA tiles in `splitk` parts, then tiles in SB parts
     FastDiv dSB;
     int32_t B, Ti, Hi, Wi, kt, nchunk, splitk, tiles_w_n, tiles_h_n;
@@ -103,7 +118,7 @@ struct P3Params {
 
 template <int N_> struct WaitVmP;
 #define MV2_WAITVMP(n) template <> struct WaitVmP<n> { static __device__ __forceinline__ void run() { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } };
-MV2_WAITVMP(0) MV2_WAITVMP(6)
+MV2_WAITVMP(0) MV2_WAITVMP(6) MV2_WAITVMP(9)
 #undef MV2_WAITVMP
 
 }  // namespace
@@ -138,6 +153,10 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     const int cs = wave & 1, kh = wave >> 1;
     const int T = p.Ti, H = p.Hi, W_ = p.Wi, kt = p.kt, pt = p.kt - 1;
     C3P_PROF_DECL
+    // PRIO: the fixed phases (prologue, exchange, slab / ticket, epilogue) run at raised issue priority, the tap loop at 0: a workgroup
+    // in a fixed phase issues little, but every instruction of it otherwise queues behind the MFMA / LDS streams of the two workgroups
+    // that share its SIMDs, and the sooner it is through the sooner the matrix pipe has three tap streams again.
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     asm volatile("" :: "s"(p.in), "s"(p.wp), "s"(p.out), "s"(p.in_bytes));      // every cache line of the kernel arguments is requested in the first round of scalar loads
 
     // ---- block -> (channel tile, batch, frame, spatial tile, K part).  XCD-aware: the blocks of one XCD walk one contiguous eighth of
@@ -169,10 +188,18 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     }
     const int co_tile = (int)fdiv(r_, pp.per_co);
     r_ -= (uint32_t)co_tile * per_co;
-    // frames are the outer loop (descending, so that the cheap causal-front frames come last and fill the tail), spatial tiles inside
-    q_ = fdiv(r_, pp.tiles_sp); const uint32_t sp = r_ - q_ * tiles_sp; r_ = q_;
-    const int b = (int)fdiv(r_, pp.T);
-    const int t = T - 1 - (int)(r_ - (uint32_t)b * (uint32_t)T);
+    // time_inner: the blocks of a spatial tile's T frames are neighbours in the list (and on one XCD), so the three output frames that read
+    // an input frame's halo run close together and two of the three reads hit that XCD's L2; otherwise frames are the outer loop
+    // (descending, so that the cheap causal-front frames come last and fill the tail).
+    uint32_t sp; int b, t;
+    if (p.time_inner) {
+        q_ = fdiv(r_, pp.T); t = T - 1 - (int)(r_ - q_ * (uint32_t)T); r_ = q_;
+        b = (int)fdiv(r_, pp.tiles_sp); sp = r_ - (uint32_t)b * tiles_sp;
+    } else {
+        q_ = fdiv(r_, pp.tiles_sp); sp = r_ - q_ * tiles_sp; r_ = q_;
+        b = (int)fdiv(r_, pp.T);
+        t = T - 1 - (int)(r_ - (uint32_t)b * (uint32_t)T);
+    }
     const int thi = (int)fdiv(sp, pp.tiles_w), twi = (int)(sp - (uint32_t)thi * (uint32_t)p.tiles_w_n);
     const int v = min(t, pt) + 1;                                       // valid time taps of this output frame (causal front)
     const uint32_t ng = (uint32_t)(p.nchunk * v);                       // groups of nine taps in the tile: (chunk, time tap), chunk-major
@@ -278,6 +305,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     read_p(pb, 0, IC<0>{});
     C3P_SUBP(6)
     C3P_PROF(0)
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(0);
 
     for (int gi = gb; gi < ge; ++gi) {
         const int par = (gi - gb) & 1;
@@ -290,22 +318,23 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         const uint32_t so1 = gbase_of(c1, i1);
         // the weight prefetch past the part's last group is never consumed: it goes through a zero-length descriptor (no memory access, the
         // ring keeps its instruction count), so the drain behind the loop does not wait for six L2 round trips nobody needs
-        const __amdgpu_buffer_rsrc_t rs_wn = live1 ? rs_w : __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wn = (live1 || MV2_C3P_WDEAD == 0) ? rs_w : __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0, 0x00020000);
         // one k-step: fragment F = 2 tap + s of the group lives in ring slot F % RING (requested RING fragments ago), pset[s] holds
         // its position fragments (read one k-step ago).  The reload of the slot goes out right behind its MFMAs.
         auto kstep = [&](auto f_c) {
             constexpr int F = decltype(f_c)::value, S_ = F & 1, SLOT = F % RING, G = F + RING;
             constexpr int NT = (F + 1) >> 1, NS = (F + 1) & 1, NOFF = ((NT / 3) * HWD + (NT % 3)) * ROWP + NS * 32;
-            // one fragment read of the NEXT k-step in each MFMA gap (a single wave then issues an MFMA every ~34 clocks instead of
+            // ILV: one fragment read of the NEXT k-step in each MFMA gap (a single wave then issues an MFMA every ~34 clocks instead of
             // one burst of four reads per four MFMAs: measured 333 clocks per tap solo with the burst form, 256 is the pipe's floor).
             // k-step 16 keeps the burst form so that this group's last reads are long done at the boundary's lgkmcnt(0).
-            constexpr bool ILV = F != 16 && F != 17;
+            constexpr bool ILV = MV2_C3P_ILV != 0 && F != 16 && F != 17;
             if constexpr (F == 17) {
                 // group boundary: the next image is complete (this wave's pieces: every load older than the last RING has landed;
                 // everybody's: the barrier), and nobody reads this group's image any more (its last fragments are in registers)
                 WaitVmP<RING>::run();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (MV2_C3P_ABL < 2) __builtin_amdgcn_s_barrier();
+                if constexpr (MV2_C3P_ILV == 0) read_p(pbn, 0, IC<0>{});
             } else if constexpr (!ILV) {
                 read_p(pbc, NOFF, IC<NS>{});
             }
@@ -313,14 +342,16 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
 #pragma unroll
             for (int bb = 0; bb < WPOS; ++bb) {
                 Mma<E>::run(wring[SLOT], pset[S_][bb], acc[bb]);
-                if constexpr (ILV) { pset[NS][bb] = *(const i32x4*)(smem + pbc[bb] + NOFF); __builtin_amdgcn_sched_barrier(0); }
-                if constexpr (F == 17) { pset[0][bb] = *(const i32x4*)(smem + pbn[bb]); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (ILV && MV2_C3P_ABL < 4) { pset[NS][bb] = *(const i32x4*)(smem + pbc[bb] + NOFF); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (ILV && MV2_C3P_ABL >= 4) { pset[NS][bb] = pset[S_][bb]; asm volatile("" : "+v"(pset[NS][bb])); }
+                if constexpr (F == 17 && MV2_C3P_ILV != 0) { pset[0][bb] = *(const i32x4*)(smem + pbn[bb]); __builtin_amdgcn_sched_barrier(0); }
             }
             const uint32_t so = G < 18 ? cur_wb + (uint32_t)(G >> 1) * tapstride + (uint32_t)(G & 1) * 1024u
                                        : nxt_wb + (uint32_t)((G - 18) >> 1) * tapstride + (uint32_t)(G & 1) * 1024u;
-            if constexpr (G < 18) issue_w(so, wring[SLOT]);
+            if constexpr (MV2_C3P_ABL >= 3) asm volatile("" : "+v"(wring[SLOT]));
+            else if constexpr (G < 18) issue_w(so, wring[SLOT]);
             else wring[SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rs_wn, (int)w_voff, (int)so, 0);
-            if constexpr (F < PPW) dma_piece(rs1, so1, par ^ 1, IC<F>{});
+            if constexpr (F < PPW && MV2_C3P_ABL < 1) dma_piece(rs1, so1, par ^ 1, IC<F>{});
             __builtin_amdgcn_sched_barrier(0);
         };
         kstep(IC<0>{}); kstep(IC<1>{}); kstep(IC<2>{}); kstep(IC<3>{}); kstep(IC<4>{}); kstep(IC<5>{});
@@ -330,6 +361,7 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
         if (gi + 2 < ge) advance1();
         nxt_wb = wbase_of(c1, i1);
     }
+    if constexpr (MV2_C3P_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     WaitVmP<0>::run();                                // every DMA write of this wave (and its trailing weight prefetch) has landed ...
     __syncthreads();                                  // ... everybody's: LDS becomes the exchange region
     // bias of this wave's 16 channels per lane (channel 32 cs + 8 g + 4 hi + j): requested now, lands under the exchange
@@ -680,7 +712,13 @@ static int launch3p(const P3Params& p, unsigned grid, hipStream_t st) {
     typedef PLds<FUSED> L;
     hipError_t e = hipFuncSetAttribute((const void*)conv3p_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kLds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3p_kernel<FUSED>), dim3(grid), dim3(256), (int)L::kLds, st, p);
+    int lds = (int)L::kLds;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e2 = getenv("MV2_C3P_LDS")) lds = std::max(lds, atoi(e2));      // occupancy sweep: 60000 -> two workgroups per CU, 90000 -> one
+    e = hipFuncSetAttribute((const void*)conv3p_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+#endif
+    hipLaunchKernelGGL((conv3p_kernel<FUSED>), dim3(grid), dim3(256), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -702,6 +740,10 @@ int conv3p_launch(const mv2_conv_desc* d, const void* in, size_t in_bytes, const
     pp.nA = P.nA; pp.tilesA = P.tilesA; pp.SB = P.SB; pp.tiles_per_xcd = P.tiles_per_xcd; pp.dSB = make_fastdiv((uint32_t)std::max(P.SB, 1));
     pp.S = make_fastdiv((uint32_t)P.splitk); pp.tiles_sp = make_fastdiv(tiles_sp); pp.T = make_fastdiv((uint32_t)d->Ti); pp.tiles_w = make_fastdiv((uint32_t)P.tiles_w);
     pp.grid = (uint32_t)grid;
+    pp.time_inner = 0;
+#ifdef MV2_EXPERIMENTS
+    if (const char* e = getenv("MV2_C3P_TIME_INNER")) pp.time_inner = atoi(e);
+#endif
     pp.B = d->B; pp.Ti = d->Ti; pp.Hi = d->Hi; pp.Wi = d->Wi; pp.kt = d->kt; pp.nchunk = P.nchunk; pp.splitk = P.splitk; pp.tiles_w_n = P.tiles_w; pp.tiles_h_n = P.tiles_h;
     pp.Ci = d->Ci; pp.co = d->co; pp.co_pad = d->co_pad; pp.out_c = d->out_c; pp.act = d->act; pp.act2 = act2;
     pp.in_bytes = (uint32_t)in_bytes; pp.w_bytes = (uint32_t)w_bytes; pp.ws_bytes = (uint32_t)P.slab_bytes; pp.se_bk = se_bk;

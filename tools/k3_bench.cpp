@@ -219,6 +219,53 @@ static bool test_shape(Shape s, int es, bool do_cpu, bool do_old, bool do_fused,
         if (rc != 0) { printf("   fused mv2_conv3 rc=%d\n", rc); ok = false; }
         std::vector<uint8_t> f_new(b.out_bytes), p_new(b.part_bytes);
         CK(hipMemcpy(f_new.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(p_new.data(), b.part, b.part_bytes, hipMemcpyDeviceToHost));
+        if (p_conv) {      // independent check of the fused stage: the plain launch (validated above) followed by the generic kernel's 1x1x1 conv + ELU, pooled SE vector on the host
+            mv2_conv_desc d1; memset(&d1, 0, sizeof(d1));
+            d1.dtype = MV2_BF16; d1.B = s.B; d1.Ti = d1.To = s.T; d1.Hi = d1.Ho = s.H; d1.Wi = d1.Wo = s.W; d1.Ci = s.C; d1.co = s.C; d1.co_pad = c.d.co_pad;
+            d1.st = d1.sh = d1.sw = 1; d1.kt = d1.kh = d1.kw = 1; d1.nsteps = s.C / 64; d1.seg_bytes = 128; d1.check_bounds = 0; d1.act = MV2_ACT_ELU; d1.store = MV2_STORE_ROWS;
+            d1.rt = d1.rh = d1.rw = 1; d1.out_c = s.C;
+            std::vector<mv2_seg> sg1(d1.nsteps); for (int i = 0; i < d1.nsteps; ++i) { sg1[i].elem_offset = i * 64; sg1[i].sel = 1u | (1u << 8) | (1u << 16); }
+            void* dsg1 = to_dev(sg1.data(), sg1.size() * sizeof(mv2_seg));
+            void *y1, *y2; CK(hipMalloc(&y1, b.out_bytes)); CK(hipMalloc(&y2, b.out_bytes));
+            CK(hipMemcpy(y1, o_new.data(), b.out_bytes, hipMemcpyHostToDevice));
+            const size_t wsb1 = p_conv_ws(&d1); void* dws1; CK(hipMalloc(&dws1, wsb1 ? wsb1 : 16));
+            rc = p_conv(&d1, y1, b.out_bytes, c.d_wp2, (const mv2_seg*)dsg1, (const float*)c.d_bias2, nullptr, nullptr, y2, dws1, wsb1, st); CK(hipStreamSynchronize(st));
+            if (rc) { printf("   reference 1x1x1 mv2_conv rc=%d\n", rc); ok = false; }
+            std::vector<uint8_t> f_ref(b.out_bytes); CK(hipMemcpy(f_ref.data(), y2, b.out_bytes, hipMemcpyDeviceToHost));
+            hipFree(y1); hipFree(y2); hipFree(dws1); hipFree(dsg1);
+            const std::vector<float> fr = to_float(f_ref, n, 2);
+            Diff d = compare(f_new, fr, 2, 2e-2, 2e-2);
+            // pooled SE vector per frame from the reference output: softmax over positions of (w . y + b), then the weighted channel means
+            const int HW = s.H * s.W;
+            std::vector<float> po((size_t)s.B * s.T * s.C);
+            for (int fi = 0; fi < s.B * s.T; ++fi) {
+                std::vector<double> lg(HW); double M = -1e300;
+                for (int q = 0; q < HW; ++q) { double a = 0.05; const float* yr = &fr[((size_t)fi * HW + q) * s.C]; for (int ch = 0; ch < s.C; ++ch) a += (double)yr[ch] * c.se_wk[ch]; lg[q] = a; M = std::max(M, a); }
+                double S = 0; std::vector<double> acc(s.C, 0.0);
+                for (int q = 0; q < HW; ++q) { const double w = exp(lg[q] - M); S += w; const float* yr = &fr[((size_t)fi * HW + q) * s.C]; for (int ch = 0; ch < s.C; ++ch) acc[ch] += w * yr[ch]; }
+                for (int ch = 0; ch < s.C; ++ch) po[(size_t)fi * s.C + ch] = (float)(acc[ch] / S);
+            }
+            const float* f = (const float*)p_new.data();
+            std::vector<float> pn((size_t)s.B * s.T * s.C);
+            for (int fi = 0; fi < s.B * s.T; ++fi) {
+                float M = -INFINITY; for (int j = 0; j < ntile; ++j) M = fmaxf(M, f[((size_t)fi * ntile + j) * (s.C + 2)]);
+                double S = 0; std::vector<double> acc(s.C, 0.0);
+                for (int j = 0; j < ntile; ++j) { const float* r = f + ((size_t)fi * ntile + j) * (s.C + 2); if (!(r[0] > -INFINITY)) continue; const double w = exp((double)r[0] - M);
+                    S += w * r[1]; for (int ch = 0; ch < s.C; ++ch) acc[ch] += w * r[2 + ch]; }
+                for (int ch = 0; ch < s.C; ++ch) pn[(size_t)fi * s.C + ch] = (float)(acc[ch] / S);
+            }
+            double dmax = 0; size_t nb = 0; for (size_t i = 0; i < pn.size(); ++i) { const double e = fabs(pn[i] - po[i]); dmax = e > dmax ? e : dmax; nb += !(e <= 2e-3 + 1e-2 * fabs(po[i])); }
+            printf("   fused vs plain + generic 1x1x1: out max|d| %.3e bad %zu; pooled SE vector max|d| %.3e bad %zu / %zu  %s\n", d.max_abs, d.nbad, dmax, nb, pn.size(), (d.nbad || nb) ? "FAIL" : "ok");
+            ok &= d.nbad == 0 && nb == 0;
+            // run-to-run: the fused launch twice more, output and records bitwise
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipMemset(b.out, 0xff, b.out_bytes)); CK(hipMemset(b.part, 0xff, b.part_bytes));
+                run_new(c, b, true, true, st); CK(hipStreamSynchronize(st));
+                std::vector<uint8_t> f2(b.out_bytes), p2(b.part_bytes);
+                CK(hipMemcpy(f2.data(), b.out, b.out_bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(p2.data(), b.part, b.part_bytes, hipMemcpyDeviceToHost));
+                if (memcmp(f2.data(), f_new.data(), b.out_bytes) != 0 || memcmp(p2.data(), p_new.data(), b.part_bytes) != 0) { printf("   FAIL: fused run %d differs bitwise from run 0\n", rep + 1); ok = false; }
+            }
+        }
         if (p_convpw) {
             CK(hipMemset(b.out, 0xff, b.out_bytes)); CK(hipMemset(b.part, 0xff, b.part_bytes));
             rc = run_old(c, b, true, true, st); CK(hipStreamSynchronize(st));
@@ -590,6 +637,18 @@ int main(int argc, char** argv) {
     const Shape small[] = {{1, 3, 12, 20, 64, 3}, {2, 2, 9, 17, 128, 3}, {1, 4, 16, 16, 256, 3}, {1, 2, 8, 8, 512, 3}, {1, 5, 4, 4, 512, 3},
                            {1, 1, 20, 36, 64, 1}, {1, 3, 10, 10, 128, 2}, {3, 1, 2, 2, 256, 3}};
     {
+    if (argc > 2 && !strcmp(argv[2], "persist")) {      // experiments library: the persistent work list forced onto shapes of a few tiles (8 / 16 / 24 workgroup slots), against the CPU reference
+        const Shape more[] = {{1, 5, 33, 50, 64, 3}, {2, 4, 20, 40, 128, 3}, {1, 6, 24, 24, 256, 3}, {1, 3, 16, 16, 512, 3}, {1, 7, 30, 30, 64, 2}, {4, 3, 16, 32, 64, 1}};
+        for (const char* sl : {"8", "16", "24"}) {
+            setenv("MV2_C3P_SLOTS", sl, 1);
+            printf("######## MV2_C3P_SLOTS=%s\n", sl);
+            for (const Shape& s : small) ok &= test_shape(s, 2, true, true, true, 0, st);
+            for (const Shape& s : more) ok &= test_shape(s, 2, true, true, true, 0, st);
+        }
+        unsetenv("MV2_C3P_SLOTS");
+        printf(ok ? "ALL OK\n" : "SOME FAILED\n");
+        return ok ? 0 : 1;
+    }
     if (!levels_only) {
         for (const Shape& s : small) ok &= test_shape(s, 2, true, true, true, 0, st);
         ok &= test_shape({1, 3, 12, 20, 64, 3}, 4, true, true, false, 0, st);
