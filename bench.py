@@ -504,10 +504,32 @@ def _main(args, lowering):
         tok.compute_dtype = torch.bfloat16
         log(f'exact fp32 mode: {exact["ms_per_step"]} ms/step')
 
+    # ---- the id-exact mode that is not 5 x slower: compute_dtype = 'split' - encoder + quantizer in fp32 storage with the
+    # ResidualUnit convolutions as split-bf16 products on the bf16 matrix pipe, decoder in the bf16 mode (magvit2_pytorch_amd/tokenizer.py)
+    id_exact = None
+    if extra_legs and not args.no_exact:
+        try:
+            tok.compute_dtype = 'split'
+            for _ in range(3):
+                cs, rs_ = step()
+            ns = 60
+            es_, (cs, rs_) = timed(step, ns, sync)
+            id_exact = dict(compute_dtype='split', frames_per_s=round(B * T / es_, 1), ms_per_step=round(es_ * 1e3, 3), steps=ns,
+                            ids_mismatch_vs_bf16_mode=round((cs != codes).float().mean().item(), 5),
+                            ids_mismatch_vs_exact_fp32_mode=None if exact is None else round((cs != c32).float().mean().item(), 5),
+                            what='encoder + quantizer: fp32 storage, ResidualUnit k3 convolutions as x_hi.w_hi + x_lo.w_hi + x_hi.w_lo on the bf16 MFMA '
+                                 '(mv2_split_bf16 + mv2_conv3 MV2_STORE_ROWS_F32), everything else on the fp32 kernels; decoder: bf16 mode from the ids')
+            log(f'id-exact split mode: {id_exact["ms_per_step"]} ms/step')
+        except Exception as e:
+            id_exact = dict(error=repr(e)[:300])
+        tok.compute_dtype = torch.bfloat16
+
     # ---- CPU baseline: the oracle restatement on this box's host cores, bounded sample of the same workload
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1 and not tokenize_only and not emu:
-        cpu_baseline = cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, (c32, r32) if exact is not None else None)
+        cpu_baseline = cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, (c32, r32) if exact is not None else None,
+                                        id_exact if (id_exact is not None and 'error' not in id_exact) else None,
+                                        (cs, rs_) if (id_exact is not None and 'error' not in id_exact) else None)
 
     out = dict(
         metric='video frames/sec encode+decode, 128x128x17f' if not tokenize_only else 'video frames/sec tokenize(), 128x128x65f FSQ',
@@ -517,7 +539,7 @@ def _main(args, lowering):
         config=dict(workload=f'{what}; ({B},3,{T},{size},{size}) clip(s) per GPU, README layer spec, random-init weights seed 0',
                     global_batch=B * world, frames_per_clip=T, parallelism=f'dp{world} (clip sharding, no data-path collective)',
                     hip_graph=not args.no_graph),
-        roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, two_streams=two_streams, exact_fp32_mode=exact, cpu_baseline=cpu_baseline)
+        roofline=roofline, batch4=batch4, configs3=configs3, configs4_fsq=configs4, two_streams=two_streams, exact_fp32_mode=exact, id_exact_mode=id_exact, cpu_baseline=cpu_baseline)
     if lowering:
         out['lowering_overrides'] = lowering       # A/B run: NOT the product's lowering
     if emu:
@@ -541,7 +563,7 @@ def _main(args, lowering):
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, exact_out):
+def cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, exact_out, id_exact=None, id_exact_out=None):
     """the reference's own forward (oracle/_ref) and the port (oracle/restate.py) on this box's host cores, bounded sample"""
     import torch
     from oracle import ref_loader
@@ -623,6 +645,10 @@ def cpu_baseline_leg(kw, cfg, sd, video, codes, recon, T, exact, exact_out):
         c32, r32 = exact_out
         exact['ids_mismatch_vs_cpu_oracle'] = round((c32[:1].cpu() != oc).float().mean().item(), 5)
         exact['recon_max_abs_diff_vs_cpu_oracle'] = round((r32[:1].cpu() - orc_recon).abs().max().item(), 7)
+    if id_exact is not None and id_exact_out is not None:
+        cs, rs_ = id_exact_out
+        id_exact['ids_mismatch_vs_cpu_oracle'] = round((cs[:1].cpu() != oc).float().mean().item(), 5)
+        id_exact['recon_mean_abs_diff_vs_cpu_oracle'] = round((rs_[:1].cpu() - orc_recon).abs().mean().item(), 6)      # the bf16 decoder's picture of the oracle's ids
     # the oracle's own bf16-autocast drift against its fp32: the yardstick for the bf16 GPU path's tolerance
     try:
         with torch.autocast('cpu', dtype=torch.bfloat16):

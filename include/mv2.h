@@ -50,7 +50,9 @@ enum {
     MV2_STORE_ROWS = 0,      /* out[row][n]                                   dense NDHWC          */
     MV2_STORE_SHUFFLE = 1,   /* depth-to-space/time: packed column n = q*Cq + c goes to
                                 position (t*rt+qt, h*rh+qh, w*rw+qw), channel c                    */
-    MV2_STORE_NCTHW_F32 = 2  /* fp32 NCTHW video with the first `crop_t` frames dropped            */
+    MV2_STORE_NCTHW_F32 = 2, /* fp32 NCTHW video with the first `crop_t` frames dropped            */
+    MV2_STORE_ROWS_F32 = 3   /* out[row][n] as fp32 out of a bf16 launch, nothing rounded: the split-bf16
+                                form of the ResidualUnit convolution (mv2_conv3 only, see mv2_split_bf16) */
 };
 
 int mv2_abi_version(void);
@@ -198,6 +200,16 @@ int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes, const voi
  * ------------------------------------------------------------------------------------------- */
 int mv2_video_to_ndhwc(int dtype, const float* in, void* out, int B, int C, int T, int H, int W,
                        int pad_t, int pad_hw, int c_pad, int tail_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mv2_split_bf16 — the input side of the id-exact 'split' mode (fp32 activations, contractions on the bf16 matrix pipe):
+ * out[row] = [ hi(x[row]) | lo(x[row]) | hi(x[row]) ], 3 C bf16 per row, hi = bf16(x) (round to nearest even), lo = bf16(x - hi).
+ * A convolution of these rows with the weight image of [ w_hi | w_hi | w_lo ] along the input channels (pack.pack_conv3d_split) is
+ *     x_hi.w_hi + x_lo.w_hi + x_hi.w_lo,
+ * every product exact in fp32 and accumulated in fp32: x.w to ~2^-17 relative per product instead of bf16's 2^-9 (reference call sites:
+ * the ResidualUnit convolutions M:937 in front of the quantizer's sign M:1705).  rows x C fp32 in, C % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int mv2_split_bf16(const float* x, void* out, int64_t rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * mv2_rms_rowscale — per-row 1 / max(||x_row||_2, 1e-12)  (fp32), the data-dependent half of

@@ -902,7 +902,8 @@ inline bool eligible3(const mv2_conv_desc& d) {
     return d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.ph == 1 && d.pw == 1 && d.kt >= 1 && d.kt <= 3 &&
            d.pt == d.kt - 1 && d.check_bounds && (d.Ci * es) % 128 == 0 && d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi &&
            d.nsteps == d.kt * 9 * ((d.Ci * es) / 128) && (d.act == MV2_ACT_NONE || d.act == MV2_ACT_ELU) && d.co >= 64 && d.co_pad % 128 == 0 &&
-           d.co <= d.co_pad && d.store == MV2_STORE_ROWS && (d.co % (16 / es)) == 0 && (d.out_c % (16 / es)) == 0 && d.out_c >= d.co;
+           d.co <= d.co_pad && (d.store == MV2_STORE_ROWS || (d.store == MV2_STORE_ROWS_F32 && d.dtype == MV2_BF16)) &&
+           (d.co % (16 / es)) == 0 && (d.out_c % (16 / es)) == 0 && d.out_c >= d.co;
 }
 
 inline Plan3 plan3(const mv2_conv_desc& d) {
@@ -981,7 +982,7 @@ static bool use_conv3p(const mv2_conv_desc& d) {
 extern "C" int mv2_conv3_eligible(const mv2_conv_desc* d) { return d && eligible3(*d) ? 1 : 0; }
 
 extern "C" int mv2_conv3_fusable(const mv2_conv_desc* d) {
-    return d && eligible3(*d) && d->dtype == MV2_BF16 && d->co == BCO && d->out_c == d->co ? 1 : 0;
+    return d && eligible3(*d) && d->dtype == MV2_BF16 && d->store == MV2_STORE_ROWS && d->co == BCO && d->out_c == d->co ? 1 : 0;
 }
 
 extern "C" size_t mv2_conv3_workspace_bytes(const mv2_conv_desc* d) {
@@ -1025,7 +1026,8 @@ extern "C" int mv2_conv3(const mv2_conv_desc* d, const void* in, size_t in_bytes
         if (act2 != MV2_ACT_NONE && act2 != MV2_ACT_ELU) return MV2_EINVAL;
     } else if (bias2 || se_part) return MV2_EINVAL;
     if (se_part && !se_wk) return MV2_EINVAL;
-    if (use_conv3p(*d))
+    if (d->store == MV2_STORE_ROWS_F32 && !conv3p_eligible(*d)) return MV2_EINVAL;      // fp32 rows out of a bf16 launch: conv3p's epilogue only
+    if (use_conv3p(*d) || d->store == MV2_STORE_ROWS_F32)
         return conv3p_launch(d, in, in_bytes, wp3, bias, wp2, bias2, act2, se_wk, se_bk, se_part, out, workspace, workspace_bytes, counters, counter_bytes,
                              (hipStream_t)stream);
     if (P.slab_bytes > 0 && (!workspace || workspace_bytes < P.slab_bytes)) return MV2_EWORKSPACE;

@@ -127,8 +127,10 @@ __device__ unsigned long long* g_conv3p_prof = nullptr;
 #define C3P_PROF_END
 #endif
 
-template <bool FUSED>
+// OUT32 (MV2_STORE_ROWS_F32, the split-bf16 form of the id-exact mode): the epilogue stores the fp32 sums (exact ELU, nothing rounded)
+template <bool FUSED, bool OUT32 = false>
 __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
+    static_assert(!(FUSED && OUT32), "the fused second stage is a bf16 stage");
     const P3Params& pp = p;
     typedef BF16 E;
     typedef PLds<FUSED> L;
@@ -432,7 +434,25 @@ __global__ __launch_bounds__(256, 3) void conv3p_kernel(const P3Params p) {
     // ---- epilogue.  own[j][4 g + q] = channel n0 + 32 cs + 8 g + 4 hi + q of position 32 (2 kh + j) + l31 of the tile.
     const int64_t frame_row0 = ((int64_t)b * T + t) * H;
     const bool elu1 = p.act == MV2_ACT_ELU;
-    if constexpr (!FUSED) {
+    if constexpr (OUT32) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ph, pw; pos_of<TW>((2 * kh + j) * 32 + l31, ph, pw);
+            const bool pos_ok = (h0 + ph) < H && (w0 + pw) < W_;
+            const int64_t m = (frame_row0 + (h0 + ph)) * W_ + (w0 + pw);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xv = own[j][4 * g + q] + bv[g][q];
+                    x[q] = elu1 ? Act<F32>::elu(xv) : xv;
+                }
+                const int n = n0 + cs * 32 + 8 * g + 4 * hi;
+                if (pos_ok && n < p.co) *(f32x4*)((char*)p.out + (m * p.out_c + n) * 4) = x;
+            }
+        }
+    } else if constexpr (!FUSED) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int ph, pw; pos_of<TW>((2 * kh + j) * 32 + l31, ph, pw);
@@ -675,12 +695,12 @@ Plan3P conv3p_plan(const mv2_conv_desc& d) {
 
 size_t conv3p_workspace_bytes(const mv2_conv_desc& d) { return conv3p_plan(d).slab_bytes; }
 
-template <bool FUSED>
+template <bool FUSED, bool OUT32 = false>
 static int launch3p(const P3Params& p, unsigned grid, hipStream_t st) {
     typedef PLds<FUSED> L;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3p_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kLds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3p_kernel<FUSED, OUT32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::kLds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3p_kernel<FUSED>), dim3(grid), dim3(256), (int)L::kLds, st, p);
+    hipLaunchKernelGGL((conv3p_kernel<FUSED, OUT32>), dim3(grid), dim3(256), (int)L::kLds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -707,6 +727,7 @@ int conv3p_launch(const mv2_conv_desc* d, const void* in, size_t in_bytes, const
     pp.in_bytes = (uint32_t)in_bytes; pp.w_bytes = (uint32_t)w_bytes; pp.ws_bytes = (uint32_t)P.slab_bytes; pp.se_bk = se_bk;
     pp.in = in; pp.wp = wp3; pp.bias = bias; pp.out = out; pp.ws = (float*)workspace; pp.counters = counters;
     pp.wp2 = wp2; pp.bias2 = bias2; pp.se_wk = se_wk; pp.se_part = se_part;
+    if (d->store == MV2_STORE_ROWS_F32) return wp2 ? MV2_EINVAL : launch3p<false, true>(pp, (unsigned)grid, st);
     return wp2 ? launch3p<true>(pp, (unsigned)grid, st) : launch3p<false>(pp, (unsigned)grid, st);
 }
 

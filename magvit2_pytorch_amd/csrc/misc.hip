@@ -73,6 +73,34 @@ __global__ __launch_bounds__(256) void rms_rowscale_kernel(const void* __restric
     }
 }
 
+// --------------------------------------------------------------------------- mv2_split_bf16
+// one thread per 4 consecutive channels: 16 bytes in, 3 x 8 bytes out (HBM-bound: 4 + 6 bytes per element)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int64_t n4, int c4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / c4; const int q = (int)(i - row * c4);
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = f2bf(v[j]); l[j] = f2bf(v[j] - bf2f(h[j])); }
+        i32x2 hv, lv;
+        hv[0] = (int)((unsigned)h[0] | ((unsigned)h[1] << 16)); hv[1] = (int)((unsigned)h[2] | ((unsigned)h[3] << 16));
+        lv[0] = (int)((unsigned)l[0] | ((unsigned)l[1] << 16)); lv[1] = (int)((unsigned)l[2] | ((unsigned)l[3] << 16));
+        unsigned short* o = out + row * (int64_t)(12 * c4) + q * 4;
+        *(i32x2*)o = hv;
+        *(i32x2*)(o + 4 * c4) = lv;
+        *(i32x2*)(o + 8 * c4) = hv;
+    }
+}
+
+extern "C" int mv2_split_bf16(const float* x, void* out, int64_t rows, int C, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || C % 4 != 0) return MV2_EINVAL;
+    const int64_t n4 = rows * (C / 4);
+    int64_t blocks = (n4 + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, n4, C / 4);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 extern "C" int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64_t rows, int C, int shift_hw, int T, void* stream) {

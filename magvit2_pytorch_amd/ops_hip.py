@@ -55,6 +55,7 @@ _SIGS = {
                             C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_video_to_ndhwc': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     'mv2_rms_rowscale': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_split_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'mv2_se_pool': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_se_gate': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
     'mv2_se_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -244,6 +245,10 @@ class HipOps:
                 _ptr(se_wk), float(se_bk), _ptr(se_part), _ptr(out), _ptr(ws), nb(ws), _ptr(counters), nb(counters))
         keep = (desc, x, wp3, bias, wp2, bias2, se_wk, se_part, out, ws, counters)
         return _mk(fn, args, 'mv2_conv3', keep, [out, se_part])
+
+    def split_bf16(self, x, out, rows, Cc):
+        fn, args = self.lib.mv2_split_bf16, (_ptr(x), _ptr(out), rows, Cc)
+        return _mk(fn, args, 'mv2_split_bf16', (x, out), [out])
 
     def copy_frames(self, src, src_T, src_t0, dst, dst_T, dst_t0, nT, B, frame_bytes):
         fn, args = self.lib.mv2_copy_frames, (_ptr(src), src_T, src_t0, _ptr(dst), dst_T, dst_t0, nT, B, frame_bytes)

@@ -26,7 +26,7 @@ import torch
 
 MV2_BF16, MV2_F32 = 0, 1
 ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU, ACT_LRELU = 0, 1, 2, 3, 4
-STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32 = 0, 1, 2
+STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32, STORE_ROWS_F32 = 0, 1, 2, 3
 FILLER_SEL = 0x80000000
 
 
@@ -171,6 +171,20 @@ def pack_conv3d(w, bias, dtype, frag_major=False):
         pc.wp = to_frag_major(pc.wp)
         pc.frag_major = True
     return pc
+
+
+def split_bf16_halves(x):
+    """x (fp32) -> (hi, lo) as fp32 tensors holding bf16 values: hi = bf16(x), lo = bf16(x - hi); x = hi + lo to ~2^-17 relative."""
+    hi = x.float().to(torch.bfloat16).float()
+    lo = (x.float() - hi).to(torch.bfloat16).float()
+    return hi, lo
+
+
+def pack_conv3d_split(w, bias):
+    """Weight image of the split-bf16 form of a k x 3 x 3 convolution (include/mv2.h mv2_split_bf16): the bf16 fragment-major image of
+    [ w_hi | w_hi | w_lo ] along the input channels, to be multiplied with rows [ x_hi | x_lo | x_hi ]: x_hi.w_hi + x_lo.w_hi + x_hi.w_lo."""
+    hi, lo = split_bf16_halves(w)
+    return pack_conv3d(torch.cat((hi, hi, lo), dim=1), bias, torch.bfloat16, frag_major=True)
 
 
 def pack_conv_in_frag(w):

@@ -69,8 +69,13 @@ PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}      # 
 
 
 class PackedModel:
-    def __init__(self, cfg: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype, ops):
+    def __init__(self, cfg: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype, ops, split_k3: bool = False):
+        """split_k3 (fp32 storage only): the ResidualUnit k x 3 x 3 convolutions additionally get the split-bf16 weight image
+        (pack.pack_conv3d_split) and their launches run x_hi.w_hi + x_lo.w_hi + x_hi.w_lo on the bf16 matrix pipe with fp32 rows in and
+        out (mv2_split_bf16 + mv2_conv3 with MV2_STORE_ROWS_F32) instead of the exact-fp32 MFMA: the id-exact mode that is not 16 x slower
+        on its dominant launches (tools/split_bf16_study.py: pre-quantizer error ~1e-6 against a sign margin of 1e-4)."""
         self.cfg, self.dtype, self.ops = cfg, dtype, ops
+        self.split_k3 = bool(split_k3) and dtype == torch.float32
         self.dt = P.dtype_code(dtype)
         self.stages: List[Stage] = parse_layers(cfg['layers'], cfg['init_dim'], cfg['max_dim'])
         # 4-channel pixels: 8-byte (bf16) / 16-byte (fp32) rows; 16-byte gathers at 8-byte alignment verified on gfx950
@@ -103,6 +108,8 @@ class PackedModel:
         def residual_unit(pre):
             w3 = f(pre + '.fn.0.conv.weight')
             put(pre + '.k3', P.pack_conv3d(w3, f(pre + '.fn.0.conv.bias'), dtype, frag_major=P.conv3_packable(w3, dtype)))
+            if self.split_k3 and P.conv3_packable(w3, torch.bfloat16):
+                put(pre + '.k3s', P.pack_conv3d_split(w3, f(pre + '.fn.0.conv.bias')))
             put(pre + '.k1', P.pack_pointwise(f(pre + '.fn.2.weight').flatten(1), f(pre + '.fn.2.bias'), dtype))
             pc1 = self.convs[pre + '.k1']
             if dtype == torch.bfloat16 and pc1.co in (128, 256, 512) and pc1.seg_bytes == 128 and pc1.co_pad == pc1.co:
@@ -465,6 +472,34 @@ class Plan:
             self.arena.put(ws)
         return out, pw_part
 
+    def _conv3_split(self, steps, pre, x: Act, k, act=P.ACT_ELU) -> Act:
+        """The ResidualUnit's k x 3 x 3 causal conv + ELU of an fp32 plan on the bf16 matrix pipe: mv2_split_bf16 turns the fp32 rows into
+        [hi | lo | hi] bf16 rows, mv2_conv3 multiplies them with the [w_hi | w_hi | w_lo] image and stores fp32 rows (MV2_STORE_ROWS_F32)."""
+        pm, ops = self.pm, self.ops
+        pc = pm.convs[pre + '.k3s']
+        xs = self.arena.get(x.rows * 3 * x.C, torch.bfloat16)
+        steps.append(ops.split_bf16(x.t, xs, x.rows, x.C))
+        steps[-1].label = pre + '.split'
+        self.step_names.append('split_bf16')
+        d = dict(dtype=P.dtype_code(torch.bfloat16), B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, Ci=3 * x.C, To=x.T, Ho=x.H, Wo=x.W, co=pc.co, co_pad=pc.co_pad,
+                 st=1, sh=1, sw=1, pt=k - 1, ph=k // 2, pw=k // 2, kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes,
+                 check_bounds=1, act=act, store=P.STORE_ROWS_F32, rt=1, rh=1, rw=1, crop_t=0, out_c=pc.co, splitk=0)
+        assert ops.conv3_eligible(d), 'the split-bf16 descriptor is not mv2_conv3-eligible'
+        out = Act(self.arena.get(x.rows * pc.co, torch.float32), x.B, x.T, x.H, x.W, pc.co)
+        ws_bytes, cnt_bytes = ops.conv3_sizes(d)
+        ws = self.arena.get((ws_bytes + 3) // 4, torch.float32) if ws_bytes > 0 else None
+        steps.append(ops.conv3(d, xs, xs.numel() * 2, pc.wp, pc.bias, out.t, ws, self._tickets(cnt_bytes)))
+        steps[-1].label = pre + '.k3(split)'
+        fl = 2.0 * x.rows * pc.co_real * (pc.k_real // 3)           # algorithmic FLOPs: the convolution's, not the three split products'
+        self.step_flops[id(steps[-1])] = fl
+        valid_taps = sum(min(t, pc.kt - 1) + 1 for t in range(x.T))
+        self.step_flops_exec[id(steps[-1])] = 3.0 * fl * valid_taps / float(x.T * pc.kt)
+        self.step_names.append(pre + '.k3(split)')
+        for t in (xs, ws):
+            if t is not None:
+                self.arena.put(t)
+        return out
+
     def _tickets(self, nbytes):
         """One zero-initialised ticket buffer shared by every mv2_conv3 launch of the plan (each launch leaves it zero)."""
         n = (int(nbytes) + 3) // 4
@@ -491,7 +526,12 @@ class Plan:
         two = _se_two_launch(Pn, C, hidden, self.dtype)
         pc3, pc1 = pm.convs[pre + '.k3'], pm.convs[pre + '.k1']
         pw_part = None
-        if pc3.frag_major:
+        if (pre + '.k3s') in pm.convs:
+            # fp32 storage, split-bf16 products (id-exact mode): the rest of the unit stays on the fp32 kernels
+            y1 = self._conv3_split(steps, pre, x, k)
+            y2 = self._conv(steps, pre + '.k1', pc1, y1, act=P.ACT_ELU, check_bounds=False)
+            self.arena.put(y1.t)
+        elif pc3.frag_major:
             # mv2_conv3; bf16 at C = 64 (a workgroup owns every channel of its positions): conv1 + ELU (+ SE pooling partials) ride along
             fuse = self.dtype == torch.bfloat16 and pc3.co == 64 and pc1.co == pc3.co and pc1.kt == 1 and OPTIONS.fuse_pw
             y1, pw_part = self._conv3(steps, pre, x, k, fuse, se_part_for=(pre if fuse and not two and OPTIONS.fuse_pool else None))

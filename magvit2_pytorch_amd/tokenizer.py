@@ -15,10 +15,13 @@ discriminator's hinge loss incl. caller-supplied multiscale discriminators.  ``v
 clips) is supported on every method.  Backward, the gradient penalty, the gradient-norm adaptive weight (training mode with a
 VGG) are out of scope here and raise ``NotImplementedError``.
 
-Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode) or
-torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode).  Default: bf16 when called
-under ``torch.autocast`` or after ``.bfloat16()``, else fp32 — mirroring how the reference gets its
-precision from the caller.
+Precision: ``compute_dtype`` = torch.float32 (fp32 storage + exact-fp32 MFMA; the id-parity mode),
+torch.bfloat16 (bf16 storage / MFMA, fp32 accumulate; the benchmark mode) or the string ``'split'`` (the id-exact mode at a third of the
+fp32 mode's time: what DECIDES the ids — the encoder and the quantizer — keeps fp32 storage and fp32 arithmetic, with its dominant
+launches, the ResidualUnit convolutions, as split-bf16 products x_hi.w_hi + x_lo.w_hi + x_hi.w_lo on the bf16 matrix pipe, fp32
+accumulate; what merely renders them — ids -> codes -> decoder — runs in the bf16 mode, so ``decode_from_code_indices(tokenize(v))``
+still equals ``forward(v)`` bit for bit).  Default: bf16 when called under ``torch.autocast`` or after ``.bfloat16()``, else fp32 —
+mirroring how the reference gets its precision from the caller.
 """
 from __future__ import annotations
 
@@ -205,7 +208,7 @@ class VideoTokenizer(nn.Module):
             raise NotImplementedError(f'channels={channels} with use_gan: the image discriminator reads 4-channel pixels; pass use_gan=False')
         self.discr = Discriminator(**dk, seed=(seed + 1) if seed is not None else None) if self.use_gan else None
 
-        self.compute_dtype: Optional[torch.dtype] = None      # None = infer (see module docstring)
+        self.compute_dtype = None                 # None = infer, torch.float32, torch.bfloat16 or 'split' (see module docstring)
         self.use_hip_graph = True
         self.max_cached_plans = 8                 # input geometries (B, T, dtype) kept resident; least recently used is dropped
         self._ops = None
@@ -359,15 +362,24 @@ class VideoTokenizer(nn.Module):
             return torch.bfloat16
         return torch.float32
 
-    def _plan(self, B, T, want_prequant=False, train=False, headless=False) -> Plan:
+    def _split_mode(self) -> bool:
+        return isinstance(self.compute_dtype, str) and self.compute_dtype == 'split'
+
+    def _plan(self, B, T, want_prequant=False, train=False, headless=False, role='all') -> Plan:
+        """role (the 'split' mode only): 'dec' = a plan whose decoder half is the one that runs (bf16 mode); anything else = the encoder /
+        quantizer / loss side (fp32 storage, split-bf16 ResidualUnit convolutions)."""
         ops = self._backend()
         dt = self._dtype()
-        kpm = (dt, self._weights_version)
+        split = False
+        if isinstance(dt, str):
+            assert dt == 'split', f"compute_dtype must be torch.float32, torch.bfloat16 or 'split', not {dt!r}"
+            dt, split = (torch.bfloat16, False) if role == 'dec' else (torch.float32, True)
+        kpm = (dt, split, self._weights_version)
         if kpm not in self._packed:
             sd = {n: self.get_parameter(n) if n != 'quantizers.mask' else self.get_buffer(n) for n in self._param_names}
-            self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops)
+            self._packed[kpm] = PackedModel(self.cfg, sd, dt, ops, split_k3=split)
         train = bool(train) and not self.use_fsq
-        kp = (dt, self._weights_version, B, T, want_prequant or train, train, bool(headless))
+        kp = (dt, split, self._weights_version, B, T, want_prequant or train, train, bool(headless))
         if kp not in self._plans:
             while len(self._plans) >= self.max_cached_plans:      # LRU: a plan owns an activation arena and up to 4 HIP graphs
                 old = next(iter(self._plans))
@@ -489,7 +501,7 @@ class VideoTokenizer(nn.Module):
     @torch.no_grad()
     def decode(self, quantized, cond=None, video_contains_first_frame=True):
         B, C, Tl, Hl, Wl = quantized.shape
-        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame)
+        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame, role='dec')
         self._set_cond(plan, cond, B)
         q = plan.quantized
         assert (C, Tl, Hl, Wl) == (q.C, q.T, q.H, q.W)
@@ -507,7 +519,7 @@ class VideoTokenizer(nn.Module):
                 f'flattened video ids must have a length ({video_code_len}) that is divisible by the fmap size ({self.fmap_size}) squared ({self.fmap_size ** 2})'
             codes = codes.reshape(codes.shape[0], -1, self.fmap_size, self.fmap_size)
         B, Tl = codes.shape[0], codes.shape[1]
-        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame)
+        plan, key = self._plan(B, self._latent_to_frames(Tl, video_contains_first_frame), headless=not video_contains_first_frame, role='dec')
         plan.ids_in.copy_(codes.reshape(-1, ncb))
         self._set_cond(plan, cond, B)
         self._run(plan, key, 'codes+dec', [plan.codes_steps, plan.dec_steps])
@@ -551,6 +563,21 @@ class VideoTokenizer(nn.Module):
                 self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
                 codes = self._ids_out(plan)
                 return (codes, plan.prequant.clone()) if return_prequant else codes
+            if self._split_mode():
+                # the ids come from the fp32 / split-bf16 encoder plan, the picture from the bf16 plan's ids -> codes -> decoder half
+                self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
+                dplan, dkey = self._plan(video.shape[0], video.shape[2], headless=not vcff, role='dec')
+                dplan.ids_in.copy_(plan.ids.reshape(dplan.ids_in.shape))
+                self._set_cond(dplan, cond, video.shape[0])
+                self._run(dplan, dkey, 'codes+dec', [dplan.codes_steps, dplan.dec_steps])
+                recon = self._recon_out(dplan)
+                if return_codes:
+                    codes = self._ids_out(plan)
+                    return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
+                if return_recon_loss_only:
+                    raise NotImplementedError("return_recon_loss_only in the 'split' mode: the loss kernels read one plan's buffers; use "
+                                              'compute_dtype=torch.float32 or torch.bfloat16 for losses')
+                return recon
             self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
             recon = self._recon_out(plan)      # image input: the reference also returns a 5-D (T = 1) reconstruction
             if return_codes:

@@ -18,7 +18,7 @@ import math
 import torch
 
 ACT_NONE, ACT_ELU, ACT_SILU, ACT_GEGLU, ACT_LRELU = 0, 1, 2, 3, 4
-STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32 = 0, 1, 2
+STORE_ROWS, STORE_SHUFFLE, STORE_NCTHW_F32, STORE_ROWS_F32 = 0, 1, 2, 3
 
 
 def _esize(t):
@@ -226,7 +226,7 @@ class CpuOps:
                 o = (torch.nn.functional.gelu(Dv[:, :, 1]) * Dv[:, :, 0]).reshape(M, hp)
                 out[: M * hp].copy_(o.reshape(-1).to(out.dtype))
                 return
-            if d['store'] == STORE_ROWS:
+            if d['store'] in (STORE_ROWS, STORE_ROWS_F32):      # ROWS_F32: `out` is an fp32 tensor, nothing is rounded
                 oc = d['out_c']
                 o = D[:, :co]
                 if residual is not None:
@@ -252,11 +252,12 @@ class CpuOps:
         return (d['dtype'] in (0, 1) and d['kh'] == 3 and d['kw'] == 3 and d['st'] == d['sh'] == d['sw'] == 1 and d['ph'] == d['pw'] == 1
                 and 1 <= d['kt'] <= 3 and d['pt'] == d['kt'] - 1 and d['check_bounds'] and (d['Ci'] * es) % 128 == 0
                 and d['To'] == d['Ti'] and d['Ho'] == d['Hi'] and d['Wo'] == d['Wi'] and d['nsteps'] == d['kt'] * 9 * ((d['Ci'] * es) // 128)
-                and d['act'] in (ACT_NONE, ACT_ELU) and d['co'] >= 64 and d['co_pad'] % 128 == 0 and d['store'] == STORE_ROWS
+                and d['act'] in (ACT_NONE, ACT_ELU) and d['co'] >= 64 and d['co_pad'] % 128 == 0
+                and (d['store'] == STORE_ROWS or (d['store'] == STORE_ROWS_F32 and d['dtype'] == 0))
                 and d['co'] % (16 // es) == 0 and d['out_c'] % (16 // es) == 0 and d['out_c'] >= d['co'])
 
     def conv3_fusable(self, d):
-        return bool(self.conv3_eligible(d) and d['dtype'] == 0 and d['co'] == 64 and d['out_c'] == d['co'])
+        return bool(self.conv3_eligible(d) and d['dtype'] == 0 and d['store'] == STORE_ROWS and d['co'] == 64 and d['out_c'] == d['co'])
 
     def conv3_sizes(self, d):
         return 0, 0
@@ -362,6 +363,17 @@ class CpuOps:
         first = ((torch.arange(rows) // shift_hw) % T) == 0
         prev[first] = 0
         return torch.cat((xr[:, : Cc // 2], prev[:, Cc // 2:]), dim=1)
+
+    def split_bf16(self, x, out, rows, Cc):
+        """include/mv2.h mv2_split_bf16: rows of [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi)"""
+        def step(stream):
+            xv = x[: rows * Cc].reshape(rows, Cc).float()
+            hi = xv.to(torch.bfloat16)
+            lo = (xv - hi.float()).to(torch.bfloat16)
+            out[: rows * 3 * Cc].copy_(torch.cat((hi, lo, hi), dim=1).reshape(-1))
+        step.outs = [out]
+        step.what = 'split_bf16'
+        return step
 
     def rms_rowscale(self, dt, x, rs, rows, Cc, shift_hw, T):
         def step(stream):
