@@ -24,7 +24,7 @@ LIB_EXP = os.path.join(HERE, 'libmv2_hip_exp.so')
 # + kernels that exist only to be measured: they live with the other experiments under tools/experiments/, not in the product source directory
 EXP_DIR = os.path.join(HERE, '..', 'tools', 'experiments')
 SOURCES_EXP = SOURCES + [os.path.join(EXP_DIR, 'exp_se.hip'), os.path.join(EXP_DIR, 'exp_attn.hip')]
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv3p.h'),
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'conv3p.h'), os.path.join(CSRC, 'conv3_knobs.h'),
            os.path.join(HERE, '..', 'include', 'mv2.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 

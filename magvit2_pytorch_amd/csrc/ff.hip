@@ -394,7 +394,10 @@ inline FfPlan ff_plan(int64_t rows, int C, int hidden_pad) {
 #endif
     P.nblk = hidden_pad / 32;
     P.tiles = (int)((rows + 63) / 64);
-    const int64_t slots = (int64_t)ff_cus() * (P.NW == 4 ? 2 : 1);      // resident workgroups (LDS: two of the 4-wave form per CU)
+    // resident workgroups per CU: two of the 4-wave form where 2 x its LDS fits (kB1 + the largest bias slice this loop may pick: S = 1),
+    // else one
+    const size_t kb1_ = C == 512 ? (size_t)FfCfg<4, 8>::kB1 : (P.NW == 8 ? (size_t)FfCfg<2, 8>::kB1 : (size_t)FfCfg<2, 4>::kB1);
+    const int64_t slots = (int64_t)ff_cus() * ((P.NW == 4 && 2 * (kb1_ + (size_t)(P.nblk + 1) * 256) <= (size_t)160 * 1024) ? 2 : 1);
     double best = 1e30; int bestS = 1;
     for (int s = 1; s <= 8; ++s) {
         if (s > 1 && 2 * (P.nblk / s) < P.NW) break;
@@ -418,15 +421,20 @@ inline FfPlan ff_plan(int64_t rows, int C, int hidden_pad) {
 
 }  // namespace
 
-extern "C" int mv2_ff_eligible(int dtype, int64_t rows, int C, int hidden_pad) { return ff_shape_ok(dtype, rows, C, hidden_pad) ? 1 : 0; }
+// The shape rule above bounds hidden_pad by 8192, the LDS does not: x tile + panels + per_max * 256 bytes of bias must fit the CU's 160 KB
+// (C = 512: kB1 is ~134 KB, i.e. hidden_pad up to ~3600 unsplit).  mv2_ff_eligible and the sizing queries say no where the plan
+// does not fit, so that a caller never commits to a launch hipFuncSetAttribute would refuse.
+inline bool ff_fits(int64_t rows, int C, int hidden_pad) { return ff_plan(rows, C, hidden_pad).lds <= (size_t)160 * 1024; }
+
+extern "C" int mv2_ff_eligible(int dtype, int64_t rows, int C, int hidden_pad) { return ff_shape_ok(dtype, rows, C, hidden_pad) && ff_fits(rows, C, hidden_pad) ? 1 : 0; }
 
 extern "C" size_t mv2_ff_workspace_bytes(int64_t rows, int C, int hidden_pad) {
-    if (!ff_shape_ok(MV2_BF16, rows, C, hidden_pad)) return 0;
+    if (!ff_shape_ok(MV2_BF16, rows, C, hidden_pad) || !ff_fits(rows, C, hidden_pad)) return 0;
     return ff_plan(rows, C, hidden_pad).slab_bytes;
 }
 
 extern "C" size_t mv2_ff_counter_bytes(int64_t rows, int C, int hidden_pad) {
-    if (!ff_shape_ok(MV2_BF16, rows, C, hidden_pad)) return 0;
+    if (!ff_shape_ok(MV2_BF16, rows, C, hidden_pad) || !ff_fits(rows, C, hidden_pad)) return 0;
     return ff_plan(rows, C, hidden_pad).counter_bytes;
 }
 
@@ -434,7 +442,7 @@ extern "C" int mv2_ff(int dtype, const void* x, const void* w1, const float* b1,
                       int C, int hidden_pad, int shift_hw, int T, void* workspace, size_t workspace_bytes, void* counters,
                       size_t counter_bytes, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !out || x == out) return MV2_EINVAL;
-    if (!ff_shape_ok(dtype, rows, C, hidden_pad)) return MV2_EINVAL;
+    if (!ff_shape_ok(dtype, rows, C, hidden_pad) || !ff_fits(rows, C, hidden_pad)) return MV2_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2) & 15)) return MV2_EINVAL;
     if (shift_hw < 0 || (shift_hw > 0 && (T <= 0 || rows % ((int64_t)shift_hw * T) != 0))) return MV2_EINVAL;
     const FfPlan P = ff_plan(rows, C, hidden_pad);

@@ -14,8 +14,12 @@
 // Round 5: the number of waves is a template parameter.  With four waves at C = 512 a wave streams 128 KB of weights through a ring of
 // 4-8 k-steps: 4-8 dependent L2 round trips, and the launch lasted 12-14 us whatever the frame count (a latency chain, not a stream).
 // With C / 32 waves (16 at C = 512, 8 at C = 256) a wave owns ONE 32-channel tile and its ring holds 16 k-steps: one or two round
-// trips for the whole GEMM; the row tile is read from LDS by every wave (16 x 32 KB at C = 512: ~0.5 us of the LDS pipe).  Results are
-// bit-identical (every output element accumulates its k-steps in the same order); profiles/r05_findings.md has the timings.
+// trips for the whole GEMM; the row tile is read from LDS by every wave (16 x 32 KB at C = 512: ~0.5 us of the LDS pipe).  The OUTPUT
+// rows are bit-identical between the two wave counts (every output element accumulates its k-steps in the same order); the SqueezeExcite
+// records are not: their exp-weighted channel sums run over NG = NT * 2 / C row groups (1 with four waves at C = 512, 4 with sixteen), so
+// the fp32 summation order - and with it the last bits of the gate and of everything downstream - follows the wave count, which the
+// launch picks from rows and batch (`wide` below: the same clip can take different orders at batch 1 and batch 4; run-to-run results of
+// one shape are bitwise reproducible).  profiles/r05_findings.md has the timings.
 #include <hip/hip_runtime.h>
 #include "common.h"
 #include "conv_common.h"

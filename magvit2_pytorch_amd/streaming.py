@@ -100,6 +100,10 @@ class ClipLanes:
         self.device = tokenizer.device
         self.on_gpu = self.device.type == 'cuda'
         self.toks = [tokenizer]
+        # NOTE: copy_for_eval() calls refresh_weights() on the ORIGINAL, which drops its packed weights, plans and captured
+        # graphs: lane 0 re-packs and re-captures on its next call.  Build the lanes before warming up (bench.py and the tests do), or call
+        # the tokenizer once afterwards.  Launch-time sizing queries (mv2_ff's workgroup split, mv2_conv3's work list) follow the CURRENT
+        # device: the lanes' calls run under torch.cuda.device(tokenizer.device), like every call of the tokenizer itself.
         for _ in range(lanes - 1):
             dup = tokenizer.copy_for_eval()
             dup.compute_dtype, dup.use_hip_graph = tokenizer.compute_dtype, tokenizer.use_hip_graph

@@ -136,6 +136,84 @@ def test_taylor_linear_attention_hand_computed_four_tokens(n, nchunk):
     assert np.abs(got - exp).max() <= (2e-5 if n <= 8 else 2e-4), np.abs(got - exp).max()
 
 
+# ------------------------------------------------------------------------------- training-mode LFQ losses and the gateloop scan: closed forms
+def test_lfq_training_losses_hand_computed_three_tokens():
+    """mv2_lfq_stats + mv2_lfq_losses against a case worked out by hand - Yu et al. 2023 section 3 (entropy penalty
+    E[H(f(z))] - gamma H(E[f(z)]) over the implicit codebook {-1, +1}^d) with the upstream conventions the reference's call site relies on
+    (M:1705; weights M:1067-1072): soft assignment prob_j = softmax_j(2 * inv_temperature * z . c_j), log clamped at 1e-5, commitment =
+    mean squared distance to the chosen code.  d = 2 -> K = 4 codes, MSB first: c_0 = (-1, -1), c_1 = (-1, +1), c_2 = (+1, -1), c_3 = (+1, +1).
+    Three tokens chosen so that the logits are the small integers (-1, -3, 3, 1), (2, -2, 2, -2) and (-4, 0, 0, 4) at inv_temperature 100."""
+    ops = _ops()
+    dev = ops.device
+    z = np.array([[0.010, -0.005], [0.0, -0.010], [0.010, 0.010]], dtype=np.float64)
+    codes = np.array([[-1, -1], [-1, 1], [1, -1], [1, 1]], dtype=np.float64)
+    inv_t, gamma, w_ent, w_commit = 100.0, 1.0, 0.1, 0.25
+    logits = 2.0 * inv_t * z @ codes.T
+    assert np.allclose(logits, [[-1, -3, 3, 1], [2, -2, 2, -2], [-4, 0, 0, 4]])
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    prob = e / e.sum(axis=1, keepdims=True)
+    ent = lambda p_: float(-(p_ * np.log(np.maximum(p_, 1e-5))).sum())
+    h_sample = np.mean([ent(prob[i]) for i in range(3)])
+    h_batch = ent(prob.mean(axis=0))
+    q = np.where(z > 0, 1.0, -1.0)                                   # strict x > 0: the zero activation quantises to -1
+    commit = float(((z - q) ** 2).mean())
+    aux = (h_sample - gamma * h_batch) * w_ent + commit * w_commit
+    pre = torch.tensor(z, dtype=torch.float32, device=dev).contiguous()
+    sums = torch.zeros(4 + 2, dtype=torch.float32, device=dev)
+    ws = torch.zeros(max(1, ops.lfq_stats_workspace_bytes(3, 2, 1) // 4), dtype=torch.float32, device=dev)
+    losses = torch.zeros(4, dtype=torch.float32, device=dev)
+    st = ops.current_stream()
+    ops.lfq_stats(pre, 3, 2, 1, inv_t, 1.0, sums, ws)(st)
+    ops.lfq_losses(sums, 3.0, 2, 1, gamma, w_ent, w_commit, losses)(st)
+    ops.synchronize()
+    got_sums, got = sums.cpu().double().numpy(), losses.cpu().double().numpy()
+    assert np.abs(got_sums[:4] - prob.sum(axis=0)).max() <= 2e-6, (got_sums[:4], prob.sum(axis=0))
+    assert abs(got_sums[4] - 3 * h_sample) <= 5e-6 and abs(got_sums[5] - ((z - q) ** 2).sum()) <= 5e-6
+    assert np.abs(got - np.array([h_sample, h_batch, commit, aux])).max() <= 5e-6, (got, [h_sample, h_batch, commit, aux])
+    # two codebooks of the same tokens: every mean is unchanged (entropies average over codebooks, the commitment over all code dims)
+    pre2 = torch.tensor(np.concatenate([z, z], axis=1), dtype=torch.float32, device=dev).contiguous()
+    sums2 = torch.zeros(2 * 4 + 2, dtype=torch.float32, device=dev)
+    ws2 = torch.zeros(max(1, ops.lfq_stats_workspace_bytes(3, 2, 2) // 4), dtype=torch.float32, device=dev)
+    ops.lfq_stats(pre2, 3, 2, 2, inv_t, 1.0, sums2, ws2)(st)
+    ops.lfq_losses(sums2, 3.0, 2, 2, gamma, w_ent, w_commit, losses)(st)
+    ops.synchronize()
+    assert np.abs(losses.cpu().double().numpy() - np.array([h_sample, h_batch, commit, aux])).max() <= 5e-6
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gateloop_scan_hand_computed_four_frames(dt):
+    """mv2_gateloop_scan against the recurrence written out by hand: per pixel and channel along time
+    h_t = sigmoid(a_t) h_{t-1} + kv_t (h_{-1} = 0), out_t = q_t h_t + residual_t (gated linear recurrence of Katsch 2023, "GateLoop", in
+    the real-valued SimpleGateLoopLayer form the reference imports at M:32 / 1221).  4 frames, 3 pixels, 8 channels, 2 clips: the scan
+    must run along TIME (row stride = pixels) and restart at every clip."""
+    ops = _ops()
+    dev = ops.device
+    B, T, Pn, Cc = 2, 4, 3, 8
+    rng = np.random.RandomState(11)
+    q, kv, a, res = (rng.uniform(-1, 1, size=(B, T, Pn, Cc)) for _ in range(4))
+    if dt == torch.bfloat16:      # the kernel reads bf16 operands: the hand computation starts from the same rounded values
+        rb = lambda x: torch.tensor(x).to(torch.bfloat16).double().numpy()
+        q, kv, a, res = rb(q), rb(kv), rb(a), rb(res)
+    exp = np.zeros((B, T, Pn, Cc))
+    for b in range(B):
+        for p_ in range(Pn):
+            for c in range(Cc):
+                h = 0.0
+                for t in range(T):
+                    h = h / (1.0 + math.exp(-a[b, t, p_, c])) + kv[b, t, p_, c]
+                    exp[b, t, p_, c] = q[b, t, p_, c] * h + res[b, t, p_, c]
+    # frame 0 has no history: out_0 = q_0 kv_0 + residual_0 whatever the gate says
+    assert np.allclose(exp[:, 0], q[:, 0] * kv[:, 0] + res[:, 0])
+    qkva = torch.tensor(np.concatenate([q, kv, a], axis=-1).reshape(B * T * Pn, 3 * Cc)).to(dt).to(dev).contiguous()
+    rt = torch.tensor(res.reshape(B * T * Pn, Cc)).to(dt).to(dev).contiguous()
+    out = torch.empty_like(rt)
+    ops.gateloop_scan(P.dtype_code(dt), qkva, rt, out, B, T, Pn, Cc)(ops.current_stream())
+    ops.synchronize()
+    got = out.cpu().double().numpy().reshape(B, T, Pn, Cc)
+    tol = 2e-6 if dt == torch.float32 else 2 ** -7 * np.abs(exp) + 1e-2
+    assert (np.abs(got - exp) <= tol).all(), np.abs(got - exp).max()
+
+
 # ------------------------------------------------------------------------------- RCCL: first contact when a multi-GPU box appears
 def _nccl_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -184,3 +262,14 @@ def test_two_rank_rccl_smoke():
     video = torch.randn(4, 3, 5, 32, 32, generator=torch.Generator().manual_seed(3))
     single = tok.tokenize(video.cuda()).cpu().numpy()
     assert np.array_equal(res[0][1], single)
+    # ... and bench.py's own N = 2 control path (respawn under torch.distributed.run, rendezvous, barriers, per-rank times, gather_codes,
+    # JSON) on the two devices, so that the first SCALE run exercises code a GPU has executed once
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', '2',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == 'weak' and len(line['per_rank_ms_per_step']) == 2

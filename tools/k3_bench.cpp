@@ -32,7 +32,8 @@ static int set_both_profiles(void* b) { int r = 0; if (p_setprof_old) r |= p_set
 static conv_fn p_conv; static ws_fn p_conv_ws, p_c3_ws, p_c3_cnt; static elig_fn p_c3_fusable; static conv3_fn p_conv3; static convpw_fn p_convpw; static tiles_fn p_c3_tiles;
 
 static uint32_t rng_state = 12345u;
-static inline float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
+static const bool g_zero_fill = getenv("K3_ZERO") != nullptr;      // K3_ZERO=1: all-zero operands (DVFS probe: the same instruction stream at the clock a quiet data path allows; rule 25 of the guide)
+static inline float frand() { rng_state = rng_state * 1664525u + 1013904223u; return g_zero_fill ? 0.f : ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
