@@ -303,6 +303,13 @@ int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames, int n, int
                   void* stream);
 int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames,
                      int n, int heads, int nchunk, void* stream);
+/* The same two launches on ONE head-major tensor qkv [frame][head][token][q 8 | k 8 | v 8] (24 elements per entry): what a single
+ * projection GEMM of [to_q | to_kv] (both read the same RMS-normed rows, M:421-430) writes with MV2_STORE_SHUFFLE, rt = heads,
+ * out_c = 24 and its packed columns ordered head-major (pack.pack_taylor_qkv).  A (frame, head) workgroup of the state kernel then reads
+ * 48 contiguous bytes per token.  out: rows x (heads*8) as above. */
+int mv2_taylor_kv_fused(int dtype, const void* qkv, float* part, int frames, int n, int heads, int nchunk, void* stream);
+int mv2_taylor_apply_fused(int dtype, const void* qkv, const float* part, void* out, float* kvsum_ws, int frames,
+                           int n, int heads, int nchunk, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantizers (third-party vector_quantize_pytorch; call sites M:1574, M:1593, M:1700, M:1705).

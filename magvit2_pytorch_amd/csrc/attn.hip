@@ -323,16 +323,24 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
 // KV state per (frame, head): [73][9] fp32, column 8 = sum of phi(k) (the normaliser).
 #define TAY_F 73
 #define TAY_S (73 * 9)
+// Where a (frame, head, token) entry of q / k / v sits, in elements.  Row layout (mv2_taylor_kv / mv2_taylor_apply): kv rows [token][k (heads x 8)
+// | v (heads x 8)], q rows [token][heads x 8].  Fused head-major layout (mv2_taylor_kv_fused / mv2_taylor_apply_fused): ONE tensor
+// [frame][head][token][q 8 | k 8 | v 8] written by the projection GEMM's depth-to-time store (MV2_STORE_SHUFFLE with rt = heads): a
+// (frame, head) workgroup of the state kernel then streams 48 contiguous bytes per token instead of two 16-byte pieces out of a 512-byte row
+// (80 MB fetched for a 10.5 MB kv tensor in the PMC pass of round 5).
+struct TayLay { int64_t frame; int64_t head; int tok; int a_off; int b_off; };
+__host__ __device__ inline TayLay tay_rows_kv(int n, int heads) { return TayLay{(int64_t)n * 2 * heads * 8, 8, 2 * heads * 8, 0, heads * 8}; }
+__host__ __device__ inline TayLay tay_rows_q(int n, int heads) { return TayLay{(int64_t)n * heads * 8, 8, heads * 8, 0, 0}; }
+__host__ __device__ inline TayLay tay_fused(int n, int heads) { return TayLay{(int64_t)heads * n * 24, (int64_t)n * 24, 24, 8, 16}; }
 
 template <typename E>
 __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__ kv, float* __restrict__ part, int n, int heads,
-                                                        int nchunk) {
+                                                        int nchunk, const TayLay L) {
     const int f = blockIdx.y, j = blockIdx.x;
     const int h = threadIdx.x >> 3, i = threadIdx.x & 7;
     if (h >= heads) return;
     const int per = (n + nchunk - 1) / nchunk;
     const int t0 = j * per, t1 = min(n, t0 + per);
-    const int ld = 2 * heads * 8;
     float a2[8][9], a1[9], a0[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) { a1[e] = 0.f; a0[e] = 0.f;
@@ -340,12 +348,12 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
         for (int jj = 0; jj < 8; ++jj) a2[jj][e] = 0.f; }
     const float r2 = 0.70710678118654752440f;
     for (int t = t0; t < t1; ++t) {
-        const int64_t row = ((int64_t)f * n + t) * ld;
+        const int64_t row = (int64_t)f * L.frame + (int64_t)h * L.head + (int64_t)t * L.tok;
         float k[8], v[9];
 #pragma unroll
         for (int c = 0; c < 8 / E::kVec; ++c) {
-            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16), k + c * E::kVec);
-            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16), v + c * E::kVec);
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + L.a_off) * E::kBytes + c * 16), k + c * E::kVec);
+            Chunk<E>::unpack(*(const i32x4*)((const char*)kv + (row + L.b_off) * E::kBytes + c * 16), v + c * E::kVec);
         }
         v[8] = 1.f;
         float ki = k[0];
@@ -380,11 +388,11 @@ __global__ __launch_bounds__(256) void taylor_kv_kernel(const void* __restrict__
 // 32 partial states meet through three xor-shuffles inside a wave (lanes l, l ^ 8, l ^ 16, l ^ 32 hold the same i) and one LDS round
 // across the four waves, summed in a fixed order (bitwise reproducible).
 template <typename E>
-__global__ __launch_bounds__(256) void taylor_kv_frame_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads) {
+__global__ __launch_bounds__(256) void taylor_kv_frame_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads,
+                                                              const TayLay L) {
     __shared__ float red[4][8][92];
     const int f = blockIdx.y, h = blockIdx.x;
     const int tid = threadIdx.x, i = tid & 7, tg = tid >> 3, wave = tid >> 6;
-    const int ld = 2 * heads * 8;
     constexpr int NC = 8 / E::kVec, U = 4;
     float a2[8][9], a1[9], a0[9];
 #pragma unroll
@@ -397,11 +405,11 @@ __global__ __launch_bounds__(256) void taylor_kv_frame_kernel(const void* __rest
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + 32 * u, n - 1);                  // clamped: the tail trip re-reads a valid row and is masked below
-            const int64_t row = ((int64_t)f * n + t) * ld;
+            const int64_t row = (int64_t)f * L.frame + (int64_t)h * L.head + (int64_t)t * L.tok;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                kr[u][c] = *(const i32x4*)((const char*)kv + (row + h * 8) * E::kBytes + c * 16);
-                vr[u][c] = *(const i32x4*)((const char*)kv + (row + (heads + h) * 8) * E::kBytes + c * 16);
+                kr[u][c] = *(const i32x4*)((const char*)kv + (row + L.a_off) * E::kBytes + c * 16);
+                vr[u][c] = *(const i32x4*)((const char*)kv + (row + L.b_off) * E::kBytes + c * 16);
             }
         }
 #pragma unroll
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256) void taylor_reduce_kernel(const float* __restr
 #define TAY_LP 12
 template <typename E>
 __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restrict__ q, const float* __restrict__ kvsum,
-                                                           void* __restrict__ out, int n, int heads) {
+                                                           void* __restrict__ out, int n, int heads, const TayLay L) {
     extern __shared__ __attribute__((aligned(16))) float kvs[];   // heads * 73 * 12
     const int f = blockIdx.y;
     const int tot = heads * TAY_S;
@@ -497,10 +505,10 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
         for (int u = 0; u < NT; ++u) {
             tok[u] = tile0 + base + u * tpb;
             const int tc = min(tok[u], n - 1);
-            const int64_t row = (int64_t)f * n + tc;
+            const int64_t qe = (int64_t)f * L.frame + (int64_t)h * L.head + (int64_t)tc * L.tok + L.a_off;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                Chunk<E>::unpack(*(const i32x4*)((const char*)q + (row * heads * 8 + h * 8) * E::kBytes + c * 16), qv[u] + c * E::kVec);
+                Chunk<E>::unpack(*(const i32x4*)((const char*)q + qe * E::kBytes + c * 16), qv[u] + c * E::kVec);
 #pragma unroll
             for (int d = 0; d < 8; ++d) qv[u][d] *= scale;
         }
@@ -569,27 +577,27 @@ __global__ __launch_bounds__(256) void taylor_apply_kernel(const void* __restric
     }
 }
 
-extern "C" int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames, int n, int heads, int nchunk, void* stream) {
+static int taylor_kv_launch(int dtype, const void* kv, float* part, int frames, int n, int heads, int nchunk, const TayLay& L, void* stream) {
     if (!kv || !part || frames <= 0 || n <= 0 || heads <= 0 || heads > 32 || nchunk <= 0 || nchunk > n) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (nchunk == 1) {      // one workgroup per (frame, head) over all tokens: `part` receives the finished states [frames][heads][657]
         dim3 gridf((unsigned)heads, (unsigned)frames);
-        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_frame_kernel<BF16>), gridf, dim3(256), 0, st, kv, part, n, heads);
-        else hipLaunchKernelGGL((taylor_kv_frame_kernel<F32>), gridf, dim3(256), 0, st, kv, part, n, heads);
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_frame_kernel<BF16>), gridf, dim3(256), 0, st, kv, part, n, heads, L);
+        else hipLaunchKernelGGL((taylor_kv_frame_kernel<F32>), gridf, dim3(256), 0, st, kv, part, n, heads, L);
         MV2_LAUNCH_CHECK();
         return MV2_OK;
     }
     dim3 grid((unsigned)nchunk, (unsigned)frames);
     const unsigned threads = (unsigned)(heads * 8);
-    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_kernel<BF16>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);
-    else hipLaunchKernelGGL((taylor_kv_kernel<F32>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_kernel<BF16>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk, L);
+    else hipLaunchKernelGGL((taylor_kv_kernel<F32>), grid, dim3(threads), 0, st, kv, part, n, heads, nchunk, L);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
 
-extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames, int n,
-                                int heads, int nchunk, void* stream) {
+static int taylor_apply_launch(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames, int n, int heads, int nchunk,
+                               const TayLay& L, void* stream) {
     if (!q || !part || !out || (nchunk > 1 && !kvsum_ws) || frames <= 0 || n <= 0 || heads <= 0 || 256 % heads != 0) return MV2_EINVAL;
     if (dtype != MV2_BF16 && dtype != MV2_F32) return MV2_EINVAL;
     const size_t lds = (size_t)heads * TAY_F * TAY_LP * sizeof(float);
@@ -602,8 +610,29 @@ extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, voi
         MV2_LAUNCH_CHECK();
     }
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)frames);
-    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_kernel<BF16>), grid, dim3(256), lds, st, q, kvsum, out, n, heads);
-    else hipLaunchKernelGGL((taylor_apply_kernel<F32>), grid, dim3(256), lds, st, q, kvsum, out, n, heads);
+    if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_kernel<BF16>), grid, dim3(256), lds, st, q, kvsum, out, n, heads, L);
+    else hipLaunchKernelGGL((taylor_apply_kernel<F32>), grid, dim3(256), lds, st, q, kvsum, out, n, heads, L);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
+}
+
+extern "C" int mv2_taylor_kv(int dtype, const void* kv, float* part, int frames, int n, int heads, int nchunk, void* stream) {
+    return taylor_kv_launch(dtype, kv, part, frames, n, heads, nchunk, tay_rows_kv(n, heads), stream);
+}
+
+extern "C" int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, float* kvsum_ws, int frames, int n,
+                                int heads, int nchunk, void* stream) {
+    return taylor_apply_launch(dtype, q, part, out, kvsum_ws, frames, n, heads, nchunk, tay_rows_q(n, heads), stream);
+}
+
+// the same two launches on the FUSED projection's head-major tensor qkv [frame][head][token][q 8 | k 8 | v 8] (see TayLay)
+extern "C" int mv2_taylor_kv_fused(int dtype, const void* qkv, float* part, int frames, int n, int heads, int nchunk, void* stream) {
+    return taylor_kv_launch(dtype, qkv, part, frames, n, heads, nchunk, tay_fused(n, heads), stream);
+}
+
+extern "C" int mv2_taylor_apply_fused(int dtype, const void* qkv, const float* part, void* out, float* kvsum_ws, int frames, int n,
+                                      int heads, int nchunk, void* stream) {
+    TayLay L = tay_fused(n, heads);
+    L.a_off = 0;                         // q leads the token's entry
+    return taylor_apply_launch(dtype, qkv, part, out, kvsum_ws, frames, n, heads, nchunk, L, stream);
 }

@@ -64,6 +64,8 @@ _SIGS = {
     'mv2_attention': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_int64, C.c_int64, C.c_void_p]),
     'mv2_taylor_kv': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_taylor_kv_fused': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_taylor_apply_fused': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'mv2_pack_conv3d_bytes': (C.c_size_t, [C.c_int] * 6),
     'mv2_pack_conv3d': (C.c_int, [C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_size_t]),
@@ -350,6 +352,16 @@ class HipOps:
         fn, args = self.lib.mv2_taylor_apply, (dt, _ptr(q), _ptr(part), _ptr(out), _ptr(kvsum), frames, n, heads, nchunk)
         keep = (q, part, out, kvsum)
         return _mk(fn, args, 'mv2_taylor_apply', keep, [out, kvsum] if nchunk > 1 else [out])      # nchunk == 1: kvsum is not written
+
+    def taylor_kv_fused(self, dt, kv, part, frames, n, heads, nchunk):
+        fn, args = self.lib.mv2_taylor_kv_fused, (dt, _ptr(kv), _ptr(part), frames, n, heads, nchunk)
+        keep = (kv, part)
+        return _mk(fn, args, 'mv2_taylor_kv_fused', keep, [part])
+
+    def taylor_apply_fused(self, dt, q, part, out, kvsum, frames, n, heads, nchunk):
+        fn, args = self.lib.mv2_taylor_apply_fused, (dt, _ptr(q), _ptr(part), _ptr(out), _ptr(kvsum), frames, n, heads, nchunk)
+        keep = (q, part, out, kvsum)
+        return _mk(fn, args, 'mv2_taylor_apply_fused', keep, [out, kvsum] if nchunk > 1 else [out])      # nchunk == 1: kvsum is not written
 
     def lfq(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
         fn = self.lib.mv2_lfq

@@ -187,6 +187,16 @@ def pack_conv3d_split(w, bias):
     return pack_conv3d(torch.cat((hi, hi, lo), dim=1), bias, torch.bfloat16, frag_major=True)
 
 
+def pack_taylor_qkv(wq, wkv, heads, dtype, in_scale=None):
+    """ONE projection for the linear attention's to_q and to_kv (both read the same RMS-normed rows, reference M:421-430): the packed
+    columns are ordered head-major [head][q 8 | k 8 | v 8], so that the GEMM's depth-to-time store (MV2_STORE_SHUFFLE, rt = heads, out_c = 24)
+    writes [frame][head][token][24] - the layout mv2_taylor_kv_fused / mv2_taylor_apply_fused read (include/mv2.h)."""
+    hd = heads * 8
+    assert wq.shape[0] == hd and wkv.shape[0] == 2 * hd and wq.shape[1] == wkv.shape[1]
+    q, k, v = wq.float().reshape(heads, 8, -1), wkv[:hd].float().reshape(heads, 8, -1), wkv[hd:].float().reshape(heads, 8, -1)
+    return pack_pointwise(torch.cat((q, k, v), dim=1).reshape(3 * hd, -1), None, dtype, in_scale=in_scale)
+
+
 def pack_conv_in_frag(w):
     """mv2_conv_in's weight image (include/mv2.h): w (64, ci <= 4, kt, 7, 7) -> [kt][7 ih][2 s][2 co tiles][64 lanes][8] bf16; lane l =
     (co = 32 tile + l % 32, pixel pair l // 32); element j = (pixel iw = 4 s + 2 (l // 32) + j // 4, channel j % 4); iw = 7 and

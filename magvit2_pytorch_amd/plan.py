@@ -40,6 +40,7 @@ class LoweringOptions:
     # C = 256: 46 against 53 us, 5120 rows at C = 512: 39 / 44, 81920 rows: 125 / 200, 20480 rows at C = 512: 151 / 159, 5120 token-shifted
     # rows: 43 / 51 - but 1280 token-shifted rows (20 row tiles for 256 CUs): 32 against 27.  0 forces the kernel (lockstep tests).
     fuse_ff_min_rows: int = 2560
+    fuse_qkv: bool = True          # linear attention: to_q and to_kv as ONE GEMM with a head-major store (mv2_taylor_*_fused) instead of two GEMMs
     conv_in: bool = True           # convin.hip instead of the generic gather kernel
     conv_out: bool = True          # convout.hip instead of the generic gather kernel
     convin_cpad: int = 4           # channels per input pixel of mv2_video_to_ndhwc (4: 8-byte bf16 pixels, 8: the round-1 layout)
@@ -165,6 +166,9 @@ class PackedModel:
             g = f(pre + '.norm.gamma') * (dim ** 0.5)
             put(pre + '.q', P.pack_pointwise(f(pre + '.attn.to_q.0.weight'), None, dtype, in_scale=g))
             put(pre + '.kv', P.pack_pointwise(f(pre + '.attn.to_kv.0.weight'), None, dtype, in_scale=g))
+            heads = cfg['linear_attn_heads']
+            if OPTIONS.fuse_qkv and cfg['linear_attn_dim_head'] == 8 and (24 * P.esize(dtype)) % 16 == 0:
+                put(pre + '.qkv', P.pack_taylor_qkv(f(pre + '.attn.to_q.0.weight'), f(pre + '.attn.to_kv.0.weight'), heads, dtype, in_scale=g))
             put(pre + '.out', P.pack_pointwise(f(pre + '.attn.to_out.0.weight'), None, dtype))
 
         for st in self.stages:
@@ -716,8 +720,6 @@ class Plan:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['linear_attn_heads'], cfg['linear_attn_dim_head']
         assert dh == 8, 'Taylor attention kernel is built for dim_head 8 (reference default, magvit2_pytorch.py:1079)'
-        q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
-        kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
         frames, n = x.B * x.T, x.H * x.W
         # one workgroup per (frame, head) accumulates the whole frame's state (mv2_taylor_kv with nchunk = 1): no partial states in HBM and no
         # reduce launch.  Only where frames x heads leaves most of the chip idle (single images, one or two frames) does the chunked form
@@ -728,10 +730,23 @@ class Plan:
         part = self.arena.get(frames * nchunk * heads * 657, torch.float32)
         kvsum = self.arena.get(frames * heads * 657, torch.float32) if nchunk > 1 else None
         o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
-        steps.append(ops.taylor_kv(self.dt, kv.t, part, frames, n, heads, nchunk))
-        steps.append(ops.taylor_apply(self.dt, q.t, part, o.t, kvsum, frames, n, heads, nchunk))
-        self.step_names += ['taylor_kv', 'taylor_apply']
-        for t in (part, kvsum, q.t, kv.t):
+        if (pre + '.qkv') in pm.convs:
+            # to_q and to_kv as ONE GEMM whose depth-to-time store writes [frame][head][token][q | k | v] (round 6): one launch less, and the
+            # state kernel streams 48 contiguous bytes per token instead of two 16-byte pieces of a 512-byte row
+            qkv = self._conv(steps, pre + '.qkv', pm.convs[pre + '.qkv'], x, rms_shift=False, check_bounds=False, store=P.STORE_SHUFFLE,
+                             shuffle=(heads, 1, 1), out_c=24)
+            steps.append(ops.taylor_kv_fused(self.dt, qkv.t, part, frames, n, heads, nchunk))
+            steps.append(ops.taylor_apply_fused(self.dt, qkv.t, part, o.t, kvsum, frames, n, heads, nchunk))
+            self.step_names += ['taylor_kv_fused', 'taylor_apply_fused']
+            free = (part, kvsum, qkv.t)
+        else:
+            q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
+            kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
+            steps.append(ops.taylor_kv(self.dt, kv.t, part, frames, n, heads, nchunk))
+            steps.append(ops.taylor_apply(self.dt, q.t, part, o.t, kvsum, frames, n, heads, nchunk))
+            self.step_names += ['taylor_kv', 'taylor_apply']
+            free = (part, kvsum, q.t, kv.t)
+        for t in free:
             if t is not None:
                 self.arena.put(t)
         out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], o, residual=x, check_bounds=False)

@@ -661,6 +661,28 @@ class CpuOps:
         step.what = 'taylor_apply'
         return step
 
+    def _qkv_fused(self, qkv, frames, n, heads):
+        """head-major fused projection output [frame][head][token][q 8 | k 8 | v 8] -> q, k, v as (f, n, h, 8)"""
+        t = qkv[: frames * heads * n * 24].reshape(frames, heads, n, 3, 8).to(self.acc).permute(0, 2, 1, 3, 4)
+        return t[..., 0, :], t[..., 1, :], t[..., 2, :]
+
+    def taylor_kv_fused(self, dt, qkv, part, frames, n, heads, nchunk):
+        def step(stream):
+            _, k, v = self._qkv_fused(qkv, frames, n, heads)
+            kv = torch.stack((k, v), dim=2).reshape(-1).to(qkv.dtype)          # rows [token][k | v]: the row-layout emulation does the rest
+            self.taylor_kv(dt, kv, part, frames, n, heads, nchunk)(stream)
+        step.outs = [part]
+        step.what = 'taylor_kv_fused'
+        return step
+
+    def taylor_apply_fused(self, dt, qkv, part, out, kvsum, frames, n, heads, nchunk):
+        def step(stream):
+            q, _, _ = self._qkv_fused(qkv, frames, n, heads)
+            self.taylor_apply(dt, q.reshape(-1).to(qkv.dtype), part, out, kvsum, frames, n, heads, nchunk)(stream)
+        step.outs = [o for o in ([out, kvsum] if nchunk > 1 else [out]) if o is not None]
+        step.what = 'taylor_apply_fused'
+        return step
+
     # ------------------------------------------------------------------ quantizers
     def lfq(self, dt, x, w_in, b_in, w_out, b_out, quantized, ids, prequant, rows, Cc, cb_dim, ncb, clamp, scale):
         def step(stream):

@@ -209,6 +209,27 @@ def test_lockstep_three_launch_se_with_fused_pooling(monkeypatch):
     run_lockstep(cfg, sd, v, torch.bfloat16)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lockstep_linear_attention_two_gemm_form(monkeypatch, dtype):
+    """The linear-attention block with to_q / to_kv as two GEMMs and the row-layout Taylor kernels (lowering option fuse_qkv off): the
+    default lowering (every other lockstep test of a spec with 'linear_attend_space') takes the fused head-major form.  Both forms are
+    compared launch by launch with the emulation, at frames of 1024 and 16 tokens and with a single frame (chunked state kernel)."""
+    monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, fuse_qkv=False))
+    for size, T, seed in ((32, 5, 21), (16, 1, 22)):
+        kw = dict(image_size=size, init_dim=64, max_dim=256, codebook_size=256,
+                  layers=('residual', 'compress_space', 'linear_attend_space', 'compress_time', 'residual', 'linear_attend_space'))
+        cfg = make_cfg(**kw)
+        sd = init_state_dict(cfg, seed=seed, randomize_se=True)
+        v = torch.randn(1, 3, T, size, size, generator=torch.Generator().manual_seed(seed + 100))
+        run_lockstep(cfg, sd, v, dtype)
+        if dtype == torch.bfloat16:
+            monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, fuse_qkv=True))
+            pm = PackedModel(cfg, sd, dtype, CpuOps())
+            assert any(k.endswith('.qkv') and 'attn' not in k for k in pm.convs) or any(k.endswith('.qkv') for k in pm.convs)
+            run_lockstep(cfg, sd, v, dtype)          # the fused form on the same model, single-frame chunked kernels included
+            monkeypatch.setattr(plan_mod, 'OPTIONS', dataclasses.replace(plan_mod.OPTIONS, fuse_qkv=False))
+
+
 def test_lockstep_fused_feed_forward(monkeypatch):
     """mv2_ff (FeedForward as one launch, csrc/ff.hip) forced at every size (the product takes it from 2560 rows on): the README spec at
     its real widths, so both kernel forms (C = 256: four waves, C = 512: eight waves), split row tiles and the token-shifted time-axis

@@ -134,6 +134,15 @@ def test_taylor_linear_attention_hand_computed_four_tokens(n, nchunk):
             f = phi(qn[t, h * dh:(h + 1) * dh] * dh ** -0.5)
             exp[t, h] = f @ KV / max(f @ Ks, 1e-5)
     assert np.abs(got - exp).max() <= (2e-5 if n <= 8 else 2e-4), np.abs(got - exp).max()
+    # the same attention through the FUSED head-major tensor [frame][head][token][q 8 | k 8 | v 8] (mv2_taylor_kv_fused / _apply_fused: what
+    # the single q | kv projection GEMM writes): same closed form, and bit-identical to the row-layout launches (same arithmetic, other addresses)
+    kk, vv = kv[:, :heads * dh].reshape(n, heads, dh), kv[:, heads * dh:].reshape(n, heads, dh)
+    qkv = torch.stack((q.reshape(n, heads, dh), kk, vv), dim=2).permute(1, 0, 2, 3).contiguous()          # (heads, n, 3, 8), one frame
+    part2, out2 = torch.empty_like(part), torch.empty_like(out)
+    ops.taylor_kv_fused(P.MV2_F32, qkv.to(dev).reshape(-1), part2, frames, n, heads, nchunk)(st)
+    ops.taylor_apply_fused(P.MV2_F32, qkv.to(dev).reshape(-1), part2, out2, kvsum, frames, n, heads, nchunk)(st)
+    ops.synchronize()
+    assert torch.equal(out2, out) and torch.equal(part2, part)
 
 
 # ------------------------------------------------------------------------------- training-mode LFQ losses and the gateloop scan: closed forms
