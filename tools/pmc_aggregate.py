@@ -57,7 +57,7 @@ def main(src, tag, dst):
         import hashlib
         h = hashlib.sha256()
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for fn in ('conv3.hip', 'conv3p.hip', 'conv3p.h', 'conv_common.h', 'common.h'):      # bench.py::kernel_source_hash
+        for fn in ('conv3.hip', 'conv3_knobs.h', 'conv3p.hip', 'conv3p.h', 'conv_common.h', 'common.h'):      # bench.py::kernel_source_hash
             with open(os.path.join(root, 'magvit2_pytorch_amd', 'csrc', fn), 'rb') as f:
                 h.update(f.read())
         js = dict(conv3_kernel_hbm_bytes_per_launch=int((2 * fetch_kb + write_kb) * 1024), launches_averaged=nf,
