@@ -32,7 +32,11 @@ static int set_both_profiles(void* b) { int r = 0; if (p_setprof_old) r |= p_set
 static conv_fn p_conv; static ws_fn p_conv_ws, p_c3_ws, p_c3_cnt; static elig_fn p_c3_fusable; static conv3_fn p_conv3; static convpw_fn p_convpw; static tiles_fn p_c3_tiles;
 
 static uint32_t rng_state = 12345u;
-static const bool g_zero_fill = getenv("K3_ZERO") != nullptr;      // K3_ZERO=1: all-zero operands (DVFS probe: the same instruction stream at the clock a quiet data path allows; rule 25 of the guide)
+// K3_ZERO=1: all-zero operands (power-management probe: the same instruction stream on a quiet data path; rule 25 of the guide);
+// K3_ZERO=x: only the activations are zero, K3_ZERO=w: only the weights (which operand path the data-dependent cost sits on)
+static const char* g_zero_env = getenv("K3_ZERO");
+static const bool g_zero_all = g_zero_env && g_zero_env[0] == '1', g_zero_x = g_zero_all || (g_zero_env && g_zero_env[0] == 'x'), g_zero_w = g_zero_all || (g_zero_env && g_zero_env[0] == 'w');
+static bool g_zero_fill = false;
 static inline float frand() { rng_state = rng_state * 1664525u + 1013904223u; return g_zero_fill ? 0.f : ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -69,7 +73,9 @@ static Case make_case(Shape s, int es) {
     c.M = (size_t)s.B * s.T * s.H * s.W;
     c.in_bytes = c.M * C * es;
     c.in.resize(c.in_bytes);
+    g_zero_fill = g_zero_x;
     for (size_t i = 0; i < c.M * C; ++i) put_elem(c.in, i, frand(), es);
+    g_zero_fill = g_zero_w;
     // plain packed weights [step][co_pad][kel], scaled so outputs are O(1)
     const float wscale = 1.0f / sqrtf((float)(27 * C) / 3.0f);
     c.wp.assign((size_t)nsteps * co_pad * 128, 0);
@@ -87,6 +93,7 @@ static Case make_case(Shape s, int es) {
                         const size_t dst = ((((size_t)st * (co_pad / 32) + g) * 4 + ks) * 2 + hf) * 512 + (size_t)r * 16;
                         memcpy(&c.wp3[dst], &c.wp[src], 16);
                     }
+    g_zero_fill = false;
     c.bias.resize(co_pad); for (auto& b : c.bias) b = frand() * 0.1f;
     // pointwise second stage (bf16 only): [C/64][co_pad][64]
     const int ns2 = C * es / 128;
