@@ -563,8 +563,9 @@ class VideoTokenizer(nn.Module):
                 self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
                 codes = self._ids_out(plan)
                 return (codes, plan.prequant.clone()) if return_prequant else codes
-            if self._split_mode():
+            if self._split_mode() and not return_recon_loss_only:
                 # the ids come from the fp32 / split-bf16 encoder plan, the picture from the bf16 plan's ids -> codes -> decoder half
+                # (return_recon_loss_only, like return_loss, stays on the ONE fp32 / split plan below: the loss kernels read one plan's buffers)
                 self._run(plan, key, 'enc+q', [plan.enc_steps, plan.q_steps])
                 dplan, dkey = self._plan(video.shape[0], video.shape[2], headless=not vcff, role='dec')
                 dplan.ids_in.copy_(plan.ids.reshape(dplan.ids_in.shape))
@@ -574,9 +575,6 @@ class VideoTokenizer(nn.Module):
                 if return_codes:
                     codes = self._ids_out(plan)
                     return (codes, recon, plan.prequant.clone()) if return_prequant else (codes, recon)
-                if return_recon_loss_only:
-                    raise NotImplementedError("return_recon_loss_only in the 'split' mode: the loss kernels read one plan's buffers; use "
-                                              'compute_dtype=torch.float32 or torch.bfloat16 for losses')
                 return recon
             self._run(plan, key, 'fwd', [plan.enc_steps, plan.q_steps, plan.dec_steps])
             recon = self._recon_out(plan)      # image input: the reference also returns a 5-D (T = 1) reconstruction

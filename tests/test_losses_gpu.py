@@ -120,6 +120,26 @@ def test_forward_return_loss_fp32_matches_oracle(kw, training):
     assert (float(br.lfq_aux_loss) != 0.) == (training and not kw.get('use_fsq', False))
 
 
+@pytest.mark.parametrize('training', [True, False])
+def test_forward_return_loss_split_mode_matches_oracle(training):
+    """forward(return_loss=True) with compute_dtype = 'split': the loss path runs on ONE plan (fp32 rows, every ResidualUnit convolution of
+    encoder AND decoder as split-bf16 products), so the scalars sit at the fp32 mode's tolerances against the oracle; 64 / 128-channel units
+    so that the split launches exist."""
+    kw = dict(image_size=32, init_dim=64, max_dim=128, codebook_size=256, layers=('residual', 'compress_space', 'residual', 'compress_time', 'residual'))
+    tok, orc = _pair(kw, 31, 'split', training)
+    v = torch.randn(2, 3, 9, 32, 32, generator=torch.Generator().manual_seed(32))
+    ototal, d = orc.forward_loss(v, training=training)
+    for rep in range(3):                                               # eager, warm, graph replay
+        total, br = tok(v.cuda(), return_loss=True)
+        qb = br.quantizer_loss_breakdown
+        assert abs(float(br.recon_loss) - float(d['recon_loss'])) <= 1e-4 * float(d['recon_loss'])
+        for name in ('per_sample_entropy', 'batch_entropy', 'commitment'):
+            assert abs(float(getattr(qb, name)) - float(d[name])) <= 2e-4, (name, float(getattr(qb, name)), float(d[name]))
+        assert abs(float(total) - float(ototal)) <= 3e-4 * max(1., abs(float(ototal)))
+    plans = list(tok._plans.values())
+    assert len(plans) == 1 and plans[0].pm.split_k3 and sum(n == 'split_bf16' for n in plans[0].step_names) == 6
+
+
 def test_training_mode_forward_value_is_the_straight_through_form():
     """train-mode recon uses z + (q - z) — equal to q up to one fp32 rounding; ids identical to eval mode."""
     tok, _ = _pair(LOSS_KW, 23, torch.float32, True)
