@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 extern "C" int mv2_split_bf16(const float* x, void* out, int64_t rows, int C, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0 || C % 4 != 0) return MV2_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return MV2_EINVAL;      // 16-byte loads, 8-byte stores
     const int64_t n4 = rows * (C / 4);
     int64_t blocks = (n4 + 255) / 256; if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, n4, C / 4);

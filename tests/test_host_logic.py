@@ -96,6 +96,17 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     assert lib.mv2_lfq(0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, 1, 64, 17, 2, 10.0, 1.0, None) == EINVAL   # 34 code dims > 32
     assert lib.mv2_fsq_codes(0, None, None, None, None, None, None, None, 1, 64, 4, 1, None) == EINVAL
     assert lib.mv2_taylor_kv(0, ptr, ptr, 1, 4, 16, 8, None) == EINVAL                          # more chunks than tokens
+    assert lib.mv2_taylor_kv_fused(0, ptr, ptr, 1, 4, 64, 1, None) == EINVAL                    # more than 32 heads
+    assert lib.mv2_taylor_apply_fused(0, ptr, ptr, ptr, None, 1, 4, 16, 2, None) == EINVAL      # chunked state without the reduce workspace
+    # mv2_split_bf16: null / misaligned pointers, rows that are not whole 16-byte chunks
+    assert lib.mv2_split_bf16(None, ptr, 4, 64, None) == EINVAL
+    assert lib.mv2_split_bf16(ptr, ptr, 4, 62, None) == EINVAL
+    assert lib.mv2_split_bf16(ctypes.c_void_p(ptr.value + 4), ptr, 4, 64, None) == EINVAL
+    # MV2_STORE_ROWS_F32 (fp32 rows out of a bf16 launch) is mv2_conv3's: not with fp32 operands, not with the fused second stage
+    d3 = ops_hip.ConvDesc(**dict(good, store=3))
+    assert lib.mv2_conv3_eligible(ctypes.byref(d3)) == 1 and lib.mv2_conv3_fusable(ctypes.byref(d3)) == 0
+    assert lib.mv2_conv3_eligible(ctypes.byref(ops_hip.ConvDesc(**dict(good, store=3, dtype=1)))) == 0
+    assert lib.mv2_conv3(ctypes.byref(d3), ptr, 4096, ptr, None, ptr, None, 1, None, 0.0, None, ptr, None, 0, None, 0, None) == EINVAL
     # mv2_ff: null pointers, widths other than 256 / 512, fp32, a hidden width that is not whole 64-unit blocks, in-place, a token shift whose
     # frames do not tile the rows; the sizing queries are pure host functions (64 KB / 128 KB of fp32 slab per split row tile, one ticket word per tile)
     assert lib.mv2_ff(0, None, ptr, ptr, ptr, ptr, ptr, 128, 256, 704, 0, 1, None, 0, None, 0, None) == EINVAL
