@@ -117,6 +117,11 @@ size_t mv2_conv_workspace_bytes(const mv2_conv_desc* d);
  * kernel's own tile is 128 x 128 / 128 x 64 / 64 x 128 / 64 x 64 by launch size): same operands, same results, never splits K.
  * Introspection for tests and profiles; callers need not ask. */
 int mv2_conv_pointwise_dma(const mv2_conv_desc* d);
+/* 1 when mv2_conv (not mv2_conv_rms) runs this descriptor on the GATHER form of that kernel: bf16 convolutions with taps / strides / zero
+ * padding whose K steps are whole 128-byte pieces of one input row (Ci % 64 == 0, seg_bytes 128), staged stores, no GEGLU, from 32 tiles of
+ * 128 x 128 on: the space / time down-sampling convolutions (reference magvit2_pytorch.py:770-807).  The launch never splits K
+ * (mv2_conv_workspace_bytes == 0) and its result is bit-identical to the generic kernel's un-split one.  Introspection only. */
+int mv2_conv_gather_dma(const mv2_conv_desc* d);
 int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
              const float* bias, const float* rowscale, const void* residual, void* out,
              void* workspace, size_t workspace_bytes, void* stream);

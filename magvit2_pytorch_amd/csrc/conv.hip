@@ -348,9 +348,16 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // the register budget follows (nothing tied the two together)
 template <int BCO, int BPOS> struct PwDmaOcc { static constexpr int kWgs = BCO + BPOS >= 256 ? 2 : (BCO + BPOS >= 192 ? 3 : 5); };
 
-template <int BCO, int BPOS, int WCO, int WPOS, int NS, bool RMS>
+//
+// GATHER (round 6): the same pipeline for convolutions WITH taps, strides and zero padding whose K steps are whole 128-byte pieces of one
+// input row each (Ci % 64 == 0: the space / time down-sampling convolutions, reference magvit2_pytorch.py:770-807).  The only difference is
+// where a position row's 128 bytes come from: its tap origin (decoded once per row, as conv_kernel does) + the step's segment offset, and a
+// tap that falls into the padding reads the out-of-range offset, for which the DMA writes zeros.  Same stage image, same MFMA order, same
+// epilogue: bit-identical to conv_kernel's un-split result.
+template <int BCO, int BPOS, int WCO, int WPOS, int NS, bool RMS, bool GATHER = false>
 __global__ __launch_bounds__(256, (PwDmaOcc<BCO, BPOS>::kWgs)) void conv_pw_dma_kernel(const ConvParams p) {
     typedef BF16 E;
+    static_assert(!(RMS && GATHER), "the fused row norm reads whole rows: pointwise launches only");
     constexpr int NWPOS = BPOS / (32 * WPOS);
     static_assert((BCO / (32 * WCO)) * NWPOS == 4, "4 waves per block");
     constexpr int STAGE = (BCO + BPOS) * 128;
@@ -380,25 +387,73 @@ __global__ __launch_bounds__(256, (PwDmaOcc<BCO, BPOS>::kWgs)) void conv_pw_dma_
     // per-thread source offsets: load i covers rows 8 (wave + 4 i) + lane / 8 of the stage image [weight rows BCO | position rows BPOS].
     // Rows past M read the out-of-range offset (no memory access); what lands in their LDS rows only reaches output rows that are never stored.
     uint32_t voff[LPS];
+    uint32_t rowmask[LPS];                                       // GATHER: tap-validity bits of the load's position row (conv_kernel's)
+    if constexpr (GATHER) {
+        // one thread per position row decodes it (32-bit divisions, closed-form masks) into LDS, idle before the first DMA
+        uint32_t* tab = (uint32_t*)smem;        // [BPOS][2]
+        for (int r = tid; r < BPOS; r += 256) {
+            const int64_t m = m0 + r;
+            uint32_t base = 0, mk = 0;
+            if (m < p.M) {
+                int b, to, ho, wo; decode_pos<E>(d, m, b, to, ho, wo);
+                const int t_in = to * d.st - d.pt, h_in = ho * d.sh - d.ph, w_in = wo * d.sw - d.pw;
+                // wrapping 32-bit arithmetic: base + tap offset is a true offset < in_bytes < 2^32 whenever the tap is valid
+                base = ((((uint32_t)b * (uint32_t)d.Ti + (uint32_t)t_in) * (uint32_t)d.Hi + (uint32_t)h_in) * (uint32_t)d.Wi +
+                        (uint32_t)w_in) * (uint32_t)d.Ci * 2u;
+                mk = 0x00ffffffu;
+                if (d.check_bounds) {
+                    auto span = [](int in0, int k, int n) -> uint32_t {    // bits j in [0, k) with 0 <= in0 + j < n
+                        const int lo = max(0, -in0), hi_ = min(k, n - in0);
+                        return hi_ > lo ? (((1u << hi_) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    };
+                    mk = span(t_in, d.kt, d.Ti) | (span(h_in, d.kh, d.Hi) << 8) | (span(w_in, d.kw, d.Wi) << 16);
+                }
+            }
+            tab[2 * r] = base; tab[2 * r + 1] = mk;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < LPS; ++i) {
-        const int row = 8 * (wave + 4 * i) + (lane >> 3);
-        const uint32_t chunk = (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-        if (i < LPW) voff[i] = (uint32_t)(n0 + row) * 128u + chunk;
-        else {
-            const int64_t m = m0 + row - BCO;
-            voff[i] = m < p.M ? (uint32_t)m * (uint32_t)d.Ci * 2u + chunk : p.in_bytes;
+        for (int i = 0; i < LPS; ++i) {
+            const int row = 8 * (wave + 4 * i) + (lane >> 3);
+            const uint32_t chunk = (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+            if (i < LPW) { voff[i] = (uint32_t)(n0 + row) * 128u + chunk; rowmask[i] = 0u; }
+            else { voff[i] = tab[2 * (row - BCO)] + chunk; rowmask[i] = tab[2 * (row - BCO) + 1]; }
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int row = 8 * (wave + 4 * i) + (lane >> 3);
+            const uint32_t chunk = (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+            rowmask[i] = 0u;
+            if (i < LPW) voff[i] = (uint32_t)(n0 + row) * 128u + chunk;
+            else {
+                const int64_t m = m0 + row - BCO;
+                voff[i] = m < p.M ? (uint32_t)m * (uint32_t)d.Ci * 2u + chunk : p.in_bytes;
+            }
         }
     }
     const uint32_t w_step = (uint32_t)d.co_pad * 128u;
+    // GATHER: the K program (one segment per step: byte offset of the tap + channel piece, tap-selection bits) is read one step ahead of
+    // its use through the scalar cache
+    auto load_seg = [&](int s) { return p.segs[min(s, nsteps - 1)]; };
+    mv2_seg sg_next = {0, 0};
+    if constexpr (GATHER) sg_next = load_seg(0);
     auto issue = [&](int s, int stage) {          // every load unconditional: steps past the end read out of range (the check does not see soffset)
         const bool live = s < nsteps;
         const uint32_t so_w = live ? (uint32_t)s * w_step : 0u, so_x = live ? (uint32_t)s * 128u : 0u;
+        const mv2_seg sg = sg_next;
+        if constexpr (GATHER) sg_next = load_seg(s + 1);
 #pragma unroll
         for (int i = 0; i < LPS; ++i) {
             __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + 8 * (wave + 4 * i) * 128);
             if (i < LPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, (int)(live ? voff[i] : p.w_bytes), (int)so_w, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, (int)(live ? voff[i] : p.in_bytes), (int)so_x, 0, 0);
+            else if constexpr (GATHER) {
+                // the tap offset goes into the VECTOR offset: a row at the padding border has a wrapped (huge) tap origin that only becomes a
+                // true offset once the tap is added, and the range check sees the vector offset alone
+                const bool ok = live && (rowmask[i] & sg.sel) == sg.sel;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, (int)(ok ? voff[i] + (uint32_t)sg.elem_offset * 2u : p.in_bytes), 0, 0, 0);
+            } else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, dst, 16, (int)(live ? voff[i] : p.in_bytes), (int)so_x, 0, 0);
         }
     };
     f32x16 acc[WCO][WPOS];
@@ -567,6 +622,44 @@ inline bool pw_dma_rule(const mv2_conv_desc& d, int64_t tiles128, TileCfg* t) {
     return false;
 }
 
+inline bool pointwise_rows(const mv2_conv_desc& d) {
+    return d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0 &&
+           d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi;
+}
+
+// conv_pw_dma_kernel<..., GATHER> instead of conv_kernel: bf16 convolutions WITH taps / strides / zero padding whose K steps are whole
+// 128-byte pieces of one input row (Ci % 64 == 0), stored through the staged epilogue, never split over K.  On the path: the space and
+// time down-sampling convolutions (reference magvit2_pytorch.py:770-807).  Tiles as for the pointwise launches, 128 x 128 from 1024 tiles
+// on; below 32 tiles of 128 x 128 conv_kernel keeps the launch (split-K where K is long).  mv2_conv only: mv2_conv_rms stays on
+// conv_kernel / the pointwise form.  Measured on MI355X (tools/k3_bench gather, profiles/r06_gather_dma.log), conv_kernel -> this kernel,
+// us per launch at B = 1: space 64 -> 128 34.6 -> 27.2, 128 -> 256 28.0 -> 23.2, 256 -> 512 30.0 -> 26.9, time 512 -> 512 at T = 20
+// 16.5 -> 13.2, at T = 10 (conv_kernel: split-K + finish launch) 15.9 -> 11.2; at B = 4: 99.5 -> 87.3, 78.5 -> 74.6, 82.1 -> 73.8,
+// 34.2 -> 28.1, 22.3 -> 19.8.  Outputs bit-identical to conv_kernel's un-split form.
+inline bool gather_dma_pick(const mv2_conv_desc& d, TileCfg* tile) {
+    if (d.dtype != MV2_BF16 || d.splitk > 1 || pointwise_rows(d) || d.act == MV2_ACT_GEGLU) return false;
+    if (d.seg_bytes != 128 || d.Ci % 64 != 0) return false;
+    if (d.store == MV2_STORE_NCTHW_F32 || (d.out_c * 2) % 16 != 0 || d.co % 8 != 0) return false;                   // stage_ok
+    const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
+    const int64_t tiles128 = ((d.co + 127) / 128) * ((M + 127) / 128);
+    TileCfg t{0, 0};
+#ifdef MV2_EXPERIMENTS
+    if (getenv("MV2_TILE")) return false;
+    if (const char* e = getenv("MV2_GATHER_DMA")) {        // 0 = off, N = tile threshold; tile from MV2_GATHER_DMA_TILE ("bco,bpos")
+        const int thr = atoi(e);
+        if (thr <= 0 || tiles128 < thr) return false;
+        if (const char* tl = getenv("MV2_GATHER_DMA_TILE")) {
+            if (sscanf(tl, "%d,%d", &t.bco, &t.bpos) == 2) { if (tile) *tile = t; return true; }
+        }
+    }
+#endif
+    if (tiles128 >= 1024 && d.co > 64) t = {128, 128};
+    else if (tiles128 >= 200) t = d.co <= 64 ? TileCfg{64, 128} : TileCfg{128, 64};
+    else if (tiles128 >= 32) t = {64, 64};
+    else return false;
+    if (tile) *tile = t;
+    return true;
+}
+
 inline bool pw_dma_pick(const mv2_conv_desc& d, TileCfg* tile) {
 #ifdef MV2_EXPERIMENTS
     if (getenv("MV2_TILE")) return false;                                        // tools/k3_bench tile sweep of conv_kernel
@@ -589,8 +682,7 @@ inline bool pw_dma_pick(const mv2_conv_desc& d, TileCfg* tile) {
     }
 #endif
     if (d.dtype != MV2_BF16 || d.splitk > 1) return false;
-    if (!(d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0 &&
-          d.To == d.Ti && d.Ho == d.Hi && d.Wo == d.Wi)) return false;
+    if (!pointwise_rows(d)) return false;
     if (d.seg_bytes != 128 || d.Ci % 64 != 0 || d.nsteps != d.Ci / 64) return false;
     if (d.store == MV2_STORE_NCTHW_F32 || (d.out_c * 2) % 16 != 0 || d.co % 8 != 0) return false;                   // stage_ok
     const int64_t M = (int64_t)d.B * d.To * d.Ho * d.Wo;
@@ -617,6 +709,7 @@ inline bool pw_dma_ok(const mv2_conv_desc& d) { return pw_dma_pick(d, nullptr); 
 struct Launch {
     TileCfg t;
     bool dma;             // conv_pw_dma_kernel
+    bool gather;          // ... its GATHER form (taps / strides / padding)
     int n_co_tiles, n_pos_tiles, splitk, steps_per_split;
     int64_t M, ws_rows;
     int ws_cols;
@@ -645,11 +738,13 @@ inline int validate(const mv2_conv_desc& d) {
     return MV2_OK;
 }
 
-inline Launch plan_launch(const mv2_conv_desc& d) {
+inline Launch plan_launch(const mv2_conv_desc& d, bool allow_gather = true) {
     Launch L;
     L.halo = false; L.th = L.tw = L.tiles_h = L.tiles_w = L.nchunk = L.chunks_per_split = 0;
     L.M = (int64_t)d.B * d.To * d.Ho * d.Wo;
     L.dma = pw_dma_pick(d, &L.t);
+    L.gather = !L.dma && allow_gather && gather_dma_pick(d, &L.t);
+    L.dma = L.dma || L.gather;
     if (!L.dma) L.t = pick_tile(d);
     L.n_co_tiles = (d.co + L.t.bco - 1) / L.t.bco;
     L.n_pos_tiles = (int)((L.M + L.t.bpos - 1) / L.t.bpos);
@@ -689,27 +784,27 @@ int launch_cfg(const ConvParams& p, const Launch& L, hipStream_t st) {
     return MV2_OK;
 }
 
-template <int BCO, int BPOS, int WCO, int WPOS, bool RMS>
+template <int BCO, int BPOS, int WCO, int WPOS, bool RMS, bool GATHER>
 int launch_pw_dma(const ConvParams& p, const Launch& L, hipStream_t st) {
     constexpr int NS = 2;
     constexpr size_t lds_main = (size_t)NS * (BCO + BPOS) * 128, lds_epi = (size_t)StageCfg<BF16, BCO, BPOS>::kBytes;
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    hipError_t e = hipFuncSetAttribute((const void*)conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS>), dim3((unsigned)(L.n_co_tiles * L.n_pos_tiles)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_pw_dma_kernel<BCO, BPOS, WCO, WPOS, NS, RMS, GATHER>), dim3((unsigned)(L.n_co_tiles * L.n_pos_tiles)), dim3(256), lds, st, p);
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
 
-template <bool RMS>
+template <bool RMS, bool GATHER = false>
 int launch_pw_dma_tile(const ConvParams& p, const Launch& L, hipStream_t st) {
     // two stages: 128 x 128 = 64 KB of LDS = two workgroups per CU (measured better than three stages, 96 KB, one workgroup per CU, on every
     // launch with more than one tile per CU: profiles/r03_pw_dma.log: ff1 22.7 vs 29.9 us, ff2 at B = 4 47.3 vs 50.8); 128 x 64 and
     // 64 x 128 = 48 KB = three, 64 x 64 = 32 KB = five
-    if (L.t.bco == 128 && L.t.bpos == 128) return launch_pw_dma<128, 128, 2, 2, RMS>(p, L, st);
-    if (L.t.bco == 128 && L.t.bpos == 64) return launch_pw_dma<128, 64, 2, 1, RMS>(p, L, st);
-    if (L.t.bco == 64 && L.t.bpos == 128) return launch_pw_dma<64, 128, 2, 1, RMS>(p, L, st);
-    if (L.t.bco == 64 && L.t.bpos == 64 && p.d.act != MV2_ACT_GEGLU) return launch_pw_dma<64, 64, 1, 1, RMS>(p, L, st);
+    if (L.t.bco == 128 && L.t.bpos == 128) return launch_pw_dma<128, 128, 2, 2, RMS, GATHER>(p, L, st);
+    if (L.t.bco == 128 && L.t.bpos == 64) return launch_pw_dma<128, 64, 2, 1, RMS, GATHER>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 128) return launch_pw_dma<64, 128, 2, 1, RMS, GATHER>(p, L, st);
+    if (L.t.bco == 64 && L.t.bpos == 64 && p.d.act != MV2_ACT_GEGLU) return launch_pw_dma<64, 64, 1, 1, RMS, GATHER>(p, L, st);
     return MV2_EINVAL;
 }
 
@@ -718,6 +813,7 @@ int launch_dtype(const ConvParams& p, const Launch& L, hipStream_t st) {
     int rc;
     if (L.dma) {
         if constexpr (std::is_same<E, BF16>::value) {
+            if (L.gather) return p.rms_fused ? MV2_EINVAL : launch_pw_dma_tile<false, true>(p, L, st);
             return p.rms_fused ? launch_pw_dma_tile<true>(p, L, st) : launch_pw_dma_tile<false>(p, L, st);
         } else {
             return MV2_EINVAL;
@@ -754,6 +850,7 @@ static int conv_impl(const mv2_conv_desc* d, const void* in, size_t in_bytes, co
                      void* workspace, size_t workspace_bytes, void* stream, int rms_fused);
 
 extern "C" int mv2_conv_pointwise_dma(const mv2_conv_desc* d) { return d && validate(*d) == MV2_OK && pw_dma_ok(*d) ? 1 : 0; }
+extern "C" int mv2_conv_gather_dma(const mv2_conv_desc* d) { return d && validate(*d) == MV2_OK && !pw_dma_ok(*d) && gather_dma_pick(*d, nullptr) ? 1 : 0; }
 
 extern "C" int mv2_conv(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
                         const float* bias, const float* rowscale, const void* residual, void* out,
@@ -768,7 +865,7 @@ extern "C" int mv2_conv_rms_ok(const mv2_conv_desc* d) {
     if (d->store == MV2_STORE_NCTHW_F32) return 0;
     const int es = d->dtype == MV2_BF16 ? 2 : 4;
     if (((d->out_c * es) % 16) != 0 || (d->co % (16 / es)) != 0) return 0;
-    return plan_launch(*d).splitk == 1 ? 1 : 0;
+    return plan_launch(*d, false).splitk == 1 ? 1 : 0;
 }
 
 extern "C" int mv2_conv_rms(const mv2_conv_desc* d, const void* in, size_t in_bytes, const void* wp, const mv2_seg* segs,
@@ -788,7 +885,7 @@ static int conv_impl(const mv2_conv_desc* d, const void* in, size_t in_bytes, co
     const size_t w_bytes = (size_t)d->nsteps * d->co_pad * 128;
     if (w_bytes >= 0xfffffff0ull) return MV2_ETOOLARGE;
     if (residual && (d->store != MV2_STORE_ROWS || d->act == MV2_ACT_GEGLU)) return MV2_EINVAL;
-    const Launch L = plan_launch(*d);
+    const Launch L = plan_launch(*d, rms_fused == 0);
     if (d->act == MV2_ACT_GEGLU && L.t.bco == 32) return MV2_EINVAL;
     ConvParams p;
     p.d = *d; p.in = in; p.wp = wp; p.segs = segs; p.bias = bias; p.rowscale = rowscale; p.residual = residual;

@@ -38,6 +38,7 @@ _SIGS = {
     'mv2_conv': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mv2_conv_pointwise_dma': (C.c_int, [C.POINTER(ConvDesc)]),
+    'mv2_conv_gather_dma': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_rms_ok': (C.c_int, [C.POINTER(ConvDesc)]),
     'mv2_conv_rms': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mv2_conv_in_eligible': (C.c_int, [C.POINTER(ConvDesc)]),
@@ -182,6 +183,11 @@ class HipOps:
         """does mv2_conv / mv2_conv_rms run this descriptor on the LDS-DMA pointwise kernel (introspection for tests)"""
         desc = ConvDesc(**d)
         return bool(self.lib.mv2_conv_pointwise_dma(C.byref(desc)))
+
+    def conv_gather_dma(self, d: dict) -> bool:
+        """does mv2_conv run this descriptor on the gather form of the LDS-DMA kernel (taps / strides / padding; introspection for tests)"""
+        desc = ConvDesc(**d)
+        return bool(self.lib.mv2_conv_gather_dma(C.byref(desc)))
 
     def conv_rms_ok(self, d: dict) -> bool:
         desc = ConvDesc(**d)

@@ -134,7 +134,7 @@ def test_launch_rules_of_the_library_match_their_restatement():
     from oracle.ndhwc_ops import CpuOps
     lib, cpu = ops_hip.load_library(), CpuOps()
     rnd = random.Random(7)
-    n = n_dma = n_rms = 0
+    n = n_dma = n_rms = n_gather = 0
     shapes = [(1, 20, 16, 16), (1, 5, 16, 16), (1, 20, 32, 32), (4, 20, 32, 32), (1, 17, 64, 64), (1, 20, 29, 29), (2, 3, 8, 8), (1, 1, 4, 4), (1, 32, 16, 16)]
     for (B, T, H, W), Ci, co, dtype, act, store in itertools.product(shapes, (64, 128, 256, 704, 1408, 96), (64, 128, 256, 768, 2816), (0, 1), (0, 1, 2, 3), (0, 1)):
         if rnd.random() < 0.6:
@@ -153,10 +153,18 @@ def test_launch_rules_of_the_library_match_their_restatement():
             assert cpu.conv_rms_ok(v) == rms, v
             if dma:
                 assert v['dtype'] == 0 and v['kh'] == 1 and v['st'] == 1 and rms and lib.mv2_conv_workspace_bytes(ctypes.byref(desc)) == 0, v
+            # the gather form of that kernel (round 6; mv2_conv only, so mv2_conv_rms_ok above does not see it): never the pointwise launches,
+            # never split over K, whole 128-byte segments of bf16 rows, at least 32 tiles of 128 x 128
+            gather = bool(lib.mv2_conv_gather_dma(ctypes.byref(desc)))
+            if gather:
+                tiles = -(-v['co'] // 128) * -(-(v['B'] * v['To'] * v['Ho'] * v['Wo']) // 128)
+                assert not dma and v['dtype'] == 0 and v['seg_bytes'] == 128 and (v['kh'] == 3 or v['st'] == 2) and v['act'] != 3 and v['splitk'] <= 1 and tiles >= 32, v
+                assert lib.mv2_conv_workspace_bytes(ctypes.byref(desc)) == 0, v
             n += 1
             n_dma += dma
             n_rms += rms
-    assert n > 1000 and n_dma > 50 and n_rms > n_dma and n_rms < n, (n, n_dma, n_rms)
+            n_gather += gather
+    assert n > 1000 and n_dma > 50 and n_rms > n_dma and n_rms < n and n_gather > 30, (n, n_dma, n_rms, n_gather)
 
 
 def test_product_fails_loudly_without_gpu():

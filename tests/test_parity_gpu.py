@@ -650,6 +650,62 @@ def test_pointwise_dma_kernel_vs_emulation(case):
     assert (a != b).float().mean().item() < 0.03
 
 
+@pytest.mark.parametrize('case', ['space_down_ragged', 'space_down_wide', 'time_down', 'k3_same_residual', 'token_shift_rowscale', 'space_down_1024_tiles',
+                                  'below_threshold', 'narrow_channels'])
+def test_gather_dma_kernel_vs_emulation(case):
+    """conv_pw_dma_kernel<GATHER> (conv.hip, round 6: the LDS-DMA staging for convolutions WITH taps, strides and zero padding - a padded tap
+    reads the out-of-range offset and the DMA writes zeros) behind mv2_conv against the emulation, every tile of its rule: 64 x 64 - the
+    space down-sampling conv on odd extents (every border tap, tiles that end inside a frame, batch 2), the causal time down-sampling conv
+    (stride 2 in time, two padded frames in front), a 3 x 3 x 3 'same' conv with residual + ELU, a token-shifted Linear with a caller-supplied
+    row scale; 128 x 64 - the space down-sampling conv at 208 tiles, ragged; 128 x 128 - at 1024 tiles.  A 12-tile launch and a 32-channel
+    input stay on conv_kernel.  Bit-identity with conv_kernel is in profiles/r06_gather_dma.log (tools/k3_bench gather)."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    #        B  Ti  Hi   Wi   Ci   Co  kt kh kw st sh sw pt ph pw  act          res    rowscale gather
+    B, Ti, Hi, Wi, Ci, Co, kt, kh, kw, st, sh, sw, pt, ph, pw, act, res, given, gather = {
+        'space_down_ragged': (2, 5, 61, 63, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, PK.ACT_NONE, False, False, True),         # 78 tiles: 64 x 64
+        'space_down_wide': (1, 13, 62, 66, 128, 256, 1, 3, 3, 1, 2, 2, 0, 1, 1, PK.ACT_NONE, False, False, True),         # 104 x 2 = 208 tiles: 128 x 64
+        'time_down': (1, 20, 16, 16, 512, 512, 3, 1, 1, 2, 1, 1, 2, 0, 0, PK.ACT_NONE, False, False, True),               # 20 x 4 = 80 tiles, 24 steps
+        'k3_same_residual': (1, 6, 20, 21, 192, 192, 3, 3, 3, 1, 1, 1, 2, 1, 1, PK.ACT_ELU, True, False, True),           # 20 x 2 = 40 tiles, 81 steps
+        'token_shift_rowscale': (2, 5, 24, 24, 256, 384, 2, 1, 1, 1, 1, 1, 1, 0, 0, PK.ACT_LRELU, True, True, True),       # 45 x 3 = 135 tiles, half-row taps
+        'space_down_1024_tiles': (1, 8, 256, 256, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, PK.ACT_SILU, False, False, True),   # 1024 tiles: 128 x 128
+        'below_threshold': (1, 3, 29, 31, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, PK.ACT_NONE, False, False, False),          # 6 tiles: conv_kernel
+        'narrow_channels': (1, 8, 64, 64, 32, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1, PK.ACT_NONE, False, False, False),          # 64-byte segments: conv_kernel
+    }[case]
+    To, Ho, Wo = (Ti + pt - kt) // st + 1, (Hi + 2 * ph - kh) // sh + 1, (Wi + 2 * pw - kw) // sw + 1
+    M = B * To * Ho * Wo
+    if case == 'token_shift_rowscale':
+        pc = PK.pack_token_shift(torch.randn(Co, Ci, generator=g) / Ci ** 0.5, torch.randn(Co, generator=g) * 0.1, torch.bfloat16)
+    else:
+        w = torch.randn(Co, Ci, kt, kh, kw, generator=g) / (Ci * kt * kh * kw) ** 0.5
+        pc = PK.pack_conv3d(w, torch.randn(Co, generator=g) * 0.1, torch.bfloat16)
+    d = dict(dtype=PK.MV2_BF16, B=B, Ti=Ti, Hi=Hi, Wi=Wi, Ci=Ci, To=To, Ho=Ho, Wo=Wo, co=pc.co, co_pad=pc.co_pad, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
+             kt=pc.kt, kh=pc.kh, kw=pc.kw, nsteps=pc.nsteps, seg_bytes=pc.seg_bytes, check_bounds=1, act=act, store=PK.STORE_ROWS, rt=1, rh=1, rw=1, crop_t=0,
+             out_c=pc.co, splitk=0)
+    assert ops.conv_gather_dma(d) == gather and not ops.conv_pointwise_dma(d)
+    assert not ops.conv_gather_dma(dict(d, dtype=PK.MV2_F32)) and not ops.conv_gather_dma(dict(d, splitk=2))
+    wsb = ops.conv_workspace_bytes(d)
+    assert wsb == 0 or not gather                   # the LDS-DMA kernel never splits K
+    x = torch.randn(B * Ti * Hi * Wi * Ci, generator=g).to(torch.bfloat16)
+    r = torch.randn(M * pc.co, generator=g).to(torch.bfloat16) if res else None
+    rs = (torch.rand(M, generator=g) + 0.5) if given else None
+    dev = ops.device
+    segs_c, segs_g = pc.segs_tensor(Hi, Wi, Ci, 'cpu'), pc.segs_tensor(Hi, Wi, Ci, dev)
+    out_c_ = torch.full((M * pc.co,), float('nan'), dtype=torch.bfloat16)
+    out_g = torch.full((M * pc.co,), float('nan'), dtype=torch.bfloat16, device=dev)
+    cpu.conv(d, x, x.numel() * 2, pc.wp, segs_c, pc.bias, rs, r, out_c_, None)(None)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+    ops.conv(d, x.to(dev), x.numel() * 2, pc.wp.to(dev), segs_g, pc.bias.to(dev), None if rs is None else rs.to(dev), None if r is None else r.to(dev), out_g, ws)(
+        ops.current_stream())
+    ops.synchronize()
+    a, b = out_g.cpu().float(), out_c_.float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert ((a - b).abs() <= 2 ** -7 * b.abs() + 4e-3).all(), (a - b).abs().max().item()          # one bf16 ulp of the fp32-accumulated value
+    assert (a != b).float().mean().item() < 0.03
+
+
 @pytest.mark.parametrize('T,H,W,Ci,Cq,shuffle,act', [(5, 32, 32, 128, 64, (1, 2, 2), 'silu'), (17, 32, 32, 128, 128, (1, 2, 2), 'silu'), (5, 29, 29, 256, 256, (2, 1, 1), 'silu'),
                                                      (4, 33, 31, 512, 256, (1, 2, 2), 'silu'), (20, 16, 16, 256, 128, (1, 2, 2), 'none'), (3, 16, 16, 128, 64, (1, 2, 2), 'silu')])
 def test_upsample_launches_vs_emulation_and_frame_by_frame(T, H, W, Ci, Cq, shuffle, act):

@@ -527,6 +527,75 @@ static void sweep_pointwise(const char* name, int rows_t, int rows_hw, int Ci, i
     g_pw_quiet = false;
 }
 
+// generic mv2_conv on a convolution WITH taps / strides / padding (the down-sampling convolutions of the path): conv_kernel against the
+// LDS-DMA gather form of conv_pw_dma_kernel (experiments library: MV2_GATHER_DMA=0 off, =N tile threshold, MV2_GATHER_DMA_TILE "bco,bpos"),
+// outputs compared element-wise (same MFMA order: bit-identical unless conv_kernel split K)
+struct GShape { const char* name; int B, Ti, Hi, Wi, Ci, Co, kt, kh, kw, st, sh, sw, pt, ph, pw; };
+static float time_gather(const GShape& g, hipStream_t st, std::vector<uint16_t>* keep, int* splitk_ws = nullptr) {
+    mv2_conv_desc d; memset(&d, 0, sizeof(d));
+    const int nchunk = g.Ci / 64, taps = g.kt * g.kh * g.kw, nsteps = taps * nchunk, co_pad = (g.Co + 127) / 128 * 128;
+    d.dtype = MV2_BF16; d.B = g.B; d.Ti = g.Ti; d.Hi = g.Hi; d.Wi = g.Wi; d.Ci = g.Ci; d.co = g.Co; d.co_pad = co_pad;
+    d.To = (g.Ti + g.pt - g.kt) / g.st + 1;                     // causal: pads in front only
+    d.Ho = (g.Hi + 2 * g.ph - g.kh) / g.sh + 1; d.Wo = (g.Wi + 2 * g.pw - g.kw) / g.sw + 1;
+    d.st = g.st; d.sh = g.sh; d.sw = g.sw; d.pt = g.pt; d.ph = g.ph; d.pw = g.pw; d.kt = g.kt; d.kh = g.kh; d.kw = g.kw;
+    d.nsteps = nsteps; d.seg_bytes = 128; d.check_bounds = 1; d.act = MV2_ACT_NONE; d.store = MV2_STORE_ROWS; d.rt = d.rh = d.rw = 1; d.out_c = g.Co; d.splitk = 0;
+    const size_t Min = (size_t)g.B * g.Ti * g.Hi * g.Wi, M = (size_t)g.B * d.To * d.Ho * d.Wo;
+    rng_state = 4242u;
+    std::vector<uint16_t> hin(Min * g.Ci), hw((size_t)nsteps * co_pad * 64, 0);
+    for (auto& v : hin) v = f2bf(frand());
+    const float ws_ = 1.0f / sqrtf((float)(taps * g.Ci) / 3.0f);
+    for (int s = 0; s < nsteps; ++s) for (int n = 0; n < g.Co; ++n) for (int k = 0; k < 64; ++k) hw[((size_t)s * co_pad + n) * 64 + k] = f2bf(frand() * ws_);
+    std::vector<mv2_seg> segs(nsteps);
+    for (int it = 0; it < g.kt; ++it) for (int ih = 0; ih < g.kh; ++ih) for (int iw = 0; iw < g.kw; ++iw) for (int ch = 0; ch < nchunk; ++ch) {
+        mv2_seg sg; sg.elem_offset = ((it * g.Hi + ih) * g.Wi + iw) * g.Ci + ch * 64; sg.sel = (1u << it) | (1u << (8 + ih)) | (1u << (16 + iw));
+        segs[((it * g.kh + ih) * g.kw + iw) * nchunk + ch] = sg;
+    }
+    std::vector<float> bias(co_pad); for (auto& b : bias) b = frand() * 0.1f;
+    void *din = to_dev(hin.data(), hin.size() * 2), *dw = to_dev(hw.data(), hw.size() * 2), *dsegs = to_dev(segs.data(), segs.size() * 8), *dbias = to_dev(bias.data(), bias.size() * 4);
+    void* dout; CK(hipMalloc(&dout, M * g.Co * 2)); CK(hipMemset(dout, 0xff, M * g.Co * 2));
+    const size_t wsb = p_conv_ws(&d); void* dws; CK(hipMalloc(&dws, wsb ? wsb : 16));
+    if (splitk_ws) *splitk_ws = (int)(wsb >> 20);
+    auto run = [&] { return p_conv(&d, din, Min * g.Ci * 2, dw, (const mv2_seg*)dsegs, (const float*)dbias, nullptr, nullptr, dout, dws, wsb, st); };
+    int rc = run(); CK(hipStreamSynchronize(st));
+    float t = -1.f;
+    if (rc) printf("   %s: mv2_conv rc=%d\n", g.name, rc);
+    else {
+        if (keep) { keep->resize(M * g.Co); CK(hipMemcpy(keep->data(), dout, M * g.Co * 2, hipMemcpyDeviceToHost)); }
+        t = time_us(run, 20, st);
+    }
+    hipFree(din); hipFree(dw); hipFree(dsegs); hipFree(dbias); hipFree(dout); hipFree(dws);
+    return t;
+}
+static void sweep_gather(const GShape& g, hipStream_t st) {
+    std::vector<uint16_t> ref, b;
+    int wsmb = 0;
+    unsetenv("MV2_GATHER_DMA"); unsetenv("MV2_GATHER_DMA_TILE");
+    const float trule = time_gather(g, st, nullptr);
+    setenv("MV2_GATHER_DMA", "0", 1);
+    const float t0 = time_gather(g, st, &ref, &wsmb);
+    const int To = (g.Ti + g.pt - g.kt) / g.st + 1, Ho = (g.Hi + 2 * g.ph - g.kh) / g.sh + 1, Wo = (g.Wi + 2 * g.pw - g.kw) / g.sw + 1;
+    const double gf = 2.0 * g.B * To * Ho * Wo * (double)g.Co * g.Ci * g.kt * g.kh * g.kw * 1e-9;
+    printf("## %-30s %5.1f GF | rule %6.1f | conv_kernel %6.1f (%4.0f TF/s%s) |", g.name, gf, trule, t0, gf / t0 * 1e3, wsmb ? ", split-K" : "");
+    const char* tiles[] = {"128,128", "128,64", "64,128", "64,64"};
+    setenv("MV2_GATHER_DMA", "1", 1);
+    for (const char* tl : tiles) {
+        setenv("MV2_GATHER_DMA_TILE", tl, 1);
+        const float t1 = time_gather(g, st, &b);
+        size_t diff = 0, nan = 0; double maxd = 0;
+        for (size_t i = 0; i < ref.size() && i < b.size(); ++i) {
+            const float x = bf2f(ref[i]), y = bf2f(b[i]);
+            if (!(y == y)) ++nan;
+            if (ref[i] != b[i]) { ++diff; maxd = std::max(maxd, (double)fabsf(x - y)); }
+        }
+        printf(" %s %6.1f", tl, t1);
+        if (t1 < 0 || ref.size() != b.size() || nan || (diff && !wsmb) || maxd > 0.05) printf(" [BAD diff %zu maxd %.3g nan %zu]", diff, maxd, nan);
+        else if (diff) printf(" (d%zu %.2g)", diff, maxd);
+        printf(" |");
+    }
+    printf("\n"); fflush(stdout);
+    unsetenv("MV2_GATHER_DMA"); unsetenv("MV2_GATHER_DMA_TILE");
+}
+
 int main(int argc, char** argv) {
     std::string lib = argc > 1 ? argv[1] : "magvit2_pytorch_amd/libmv2_hip_exp.so";
     void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
@@ -607,6 +676,31 @@ int main(int argc, char** argv) {
         ab_pointwise("ff1 B=4 C=256 geglu+rms", 80, 32, 256, 2 * 704, MV2_ACT_GEGLU, false, st2, true);
         ab_pointwise("ff2 B=4 C=256 +res", 80, 32, 704, 256, MV2_ACT_NONE, true, st2);
         ab_pointwise("up2x2 128->128 B=4", 80, 64, 128, 512, MV2_ACT_SILU, false, st2, false, 2);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "gather")) {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        const GShape shapes[] = {
+            // the down-sampling convolutions of BASELINE configs[1] (B = 1) ...
+            {"enc1 space 64->128 128x128", 1, 20, 128, 128, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"enc3 space 128->256 64x64", 1, 20, 64, 64, 128, 256, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"enc6 space 256->512 32x32", 1, 20, 32, 32, 256, 512, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"enc9 time 512->512 T=20", 1, 20, 16, 16, 512, 512, 3, 1, 1, 2, 1, 1, 2, 0, 0},
+            {"enc11 time 512->512 T=10", 1, 10, 16, 16, 512, 512, 3, 1, 1, 2, 1, 1, 2, 0, 0},
+            // ... ragged and padded everywhere (odd extents: tiles that end inside a frame, every border tap) ...
+            {"ragged space 64->128 29x31", 2, 3, 29, 31, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"ragged k3 stride1 128 13x11", 1, 7, 13, 11, 128, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1},
+            // ... and batch 4
+            {"B4 enc1 space 64->128", 4, 20, 128, 128, 64, 128, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"B4 enc3 space 128->256", 4, 20, 64, 64, 128, 256, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"B4 enc6 space 256->512", 4, 20, 32, 32, 256, 512, 1, 3, 3, 1, 2, 2, 0, 1, 1},
+            {"B4 enc9 time 512->512 T=20", 4, 20, 16, 16, 512, 512, 3, 1, 1, 2, 1, 1, 2, 0, 0},
+            {"B4 enc11 time 512->512 T=10", 4, 10, 16, 16, 512, 512, 3, 1, 1, 2, 1, 1, 2, 0, 0},
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("---- pass %d: us per launch; conv_kernel vs conv_pw_dma_kernel<GATHER> per tile (bco,bpos)\n", rep);
+            for (const GShape& g : shapes) sweep_gather(g, st2);
+        }
         return 0;
     }
     if (argc > 2 && !strcmp(argv[2], "generic")) {
