@@ -267,7 +267,8 @@ int mv2_se_fc2_apply(int dtype, const void* y, const float* hid, const float* w2
  *   space attention: seq_inner = 1,   seq_outer_stride = n, tok_stride = 1   (s = frame)
  *   time  attention: seq_inner = H*W, seq_outer_stride = T*H*W, tok_stride = H*W (s = pixel)
  * mem_kv: fp32 (2, heads, n_mem, dim_head).  out: rows x (heads*dim_head), same row addressing.
- * dim_head must be 32 (the reference default, M:1076).
+ * dim_head: 8, 16, 32 (the reference default, M:1076) or 64.  bf16 non-causal sequences of >= 64 tokens at dim_head 32 run on the MFMA
+ * kernel; everything else (fp32, the causal time attention, the other widths) on fp32 VALU kernels.
  * ------------------------------------------------------------------------------------------- */
 int mv2_attention(int dtype, const void* qkv, const float* mem_kv, void* out, int nseq, int n, int heads,
                   int dim_head, int n_mem, int causal, int seq_inner, int64_t seq_outer_stride,
@@ -315,6 +316,13 @@ int mv2_taylor_apply(int dtype, const void* q, const float* part, void* out, flo
 int mv2_taylor_kv_fused(int dtype, const void* qkv, float* part, int frames, int n, int heads, int nchunk, void* stream);
 int mv2_taylor_apply_fused(int dtype, const void* qkv, const float* part, void* out, float* kvsum_ws, int frames,
                            int n, int heads, int nchunk, void* stream);
+/* Any supported head width: dim_head 4, 8 or 16 (the reference's linear_attn_dim_head is a free keyword, M:1079 -> 415-419; 8 is its
+ * default and the width the kernels above are tuned for — dim_head = 8 forwards to them with nchunk = 1).  phi has F = 1 + d + d^2
+ * features; `state` is [frames][heads][F][d + 1] fp32 (column d = the normaliser): mv2_taylor_state_floats(dim_head) floats per
+ * (frame, head), 0 for an unsupported width.  Row layouts as mv2_taylor_kv / mv2_taylor_apply with 8 -> dim_head. */
+size_t mv2_taylor_state_floats(int dim_head);
+int mv2_taylor_kv_d(int dtype, const void* kv, float* state, int frames, int n, int heads, int dim_head, void* stream);
+int mv2_taylor_apply_d(int dtype, const void* q, const float* state, void* out, int frames, int n, int heads, int dim_head, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantizers (third-party vector_quantize_pytorch; call sites M:1574, M:1593, M:1700, M:1705).

@@ -14,24 +14,31 @@ __device__ __forceinline__ int64_t attn_row(const AttnParams& p, int seq, int i)
     return (int64_t)(seq / p.seq_inner) * p.seq_outer_stride + (seq % p.seq_inner) + (int64_t)i * p.tok_stride;
 }
 
-template <typename E>
-__device__ __forceinline__ void load32(const void* base, int64_t elem, float* f) {
+// dim_head^-0.5 as the correctly rounded fp32 constant (what torch computes on the host: q * dim_head ** -0.5)
+template <int D> __host__ __device__ constexpr float attn_scale() {
+    static_assert(D == 8 || D == 16 || D == 32 || D == 64, "dim_head of the VALU attention kernels");
+    return D == 8 ? 0.35355339059327376220f : D == 16 ? 0.25f : D == 32 ? 0.17677669529663687f : 0.125f;
+}
+
+template <typename E, int D = 32>
+__device__ __forceinline__ void load32(const void* base, int64_t elem, float* f) {      // D elements (the name is round 1's: D was 32)
     const char* ptr = (const char*)base + elem * E::kBytes;
 #pragma unroll
-    for (int c = 0; c < 32 / E::kVec; ++c) {
+    for (int c = 0; c < D / E::kVec; ++c) {
         const i32x4 v = *(const i32x4*)(ptr + c * 16);
         Chunk<E>::unpack(v, f + c * E::kVec);
     }
 }
-template <typename E>
+template <typename E, int D = 32>
 __device__ __forceinline__ void store32(void* base, int64_t elem, const float* f) {
     char* ptr = (char*)base + elem * E::kBytes;
 #pragma unroll
-    for (int c = 0; c < 32 / E::kVec; ++c) *(i32x4*)(ptr + c * 16) = Chunk<E>::pack(f + c * E::kVec);
+    for (int c = 0; c < D / E::kVec; ++c) *(i32x4*)(ptr + c * 16) = Chunk<E>::pack(f + c * E::kVec);
 }
 
-// ---- small sequences (time attention): one thread per (seq, head, query), K/V straight from L2
-template <typename E>
+// ---- small sequences (time attention): one thread per (seq, head, query), K/V straight from L2.  D = dim_head (8 / 16 / 32 / 64: the
+// reference takes any attn_dim_head, M:1076; 32 is its default and the only width the MFMA kernel below is built for)
+template <typename E, int D>
 __global__ __launch_bounds__(256) void attn_small_kernel(const AttnParams p) {
     const int64_t total = (int64_t)p.nseq * p.heads * p.n;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,87 +46,89 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnParams p) {
     const int i = (int)(idx % p.n);
     const int h = (int)((idx / p.n) % p.heads);
     const int seq = (int)(idx / ((int64_t)p.n * p.heads));
-    const int ld = 3 * p.heads * 32;
-    float q[32], o[32];
-    load32<E>(p.qkv, attn_row(p, seq, i) * ld + h * 32, q);
+    const int ld = 3 * p.heads * D;
+    float q[D], o[D];
+    load32<E, D>(p.qkv, attn_row(p, seq, i) * ld + h * D, q);
 #pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    for (int d = 0; d < D; ++d) o[d] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int klen = p.n_mem + (p.causal ? i + 1 : p.n);
-    const float scale = 0.17677669529663687f;   // 32^-0.5
+    constexpr float scale = attn_scale<D>();
     for (int j = 0; j < klen; ++j) {
-        float k[32], v[32];
+        float k[D], v[D];
         if (j < p.n_mem) {
-            const float* mk = p.mem_kv + ((int64_t)h * p.n_mem + j) * 32;
-            const float* mv = p.mem_kv + (((int64_t)p.heads + h) * p.n_mem + j) * 32;
+            const float* mk = p.mem_kv + ((int64_t)h * p.n_mem + j) * D;
+            const float* mv = p.mem_kv + (((int64_t)p.heads + h) * p.n_mem + j) * D;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { k[d] = mk[d]; v[d] = mv[d]; }
+            for (int d = 0; d < D; ++d) { k[d] = mk[d]; v[d] = mv[d]; }
         } else {
             const int64_t r = attn_row(p, seq, j - p.n_mem) * ld;
-            load32<E>(p.qkv, r + (p.heads + h) * 32, k);
-            load32<E>(p.qkv, r + (2 * p.heads + h) * 32, v);
+            load32<E, D>(p.qkv, r + (p.heads + h) * D, k);
+            load32<E, D>(p.qkv, r + (2 * p.heads + h) * D, v);
         }
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) s += q[d] * k[d];
+        for (int d = 0; d < D; ++d) s += q[d] * k[d];
         s *= scale;
         const float mn = fmaxf(m, s);
         const float a = expf(m - mn), e = expf(s - mn);
         l = l * a + e;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) o[d] = o[d] * a + e * v[d];
+        for (int d = 0; d < D; ++d) o[d] = o[d] * a + e * v[d];
         m = mn;
     }
     const float inv = 1.f / l;
 #pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] *= inv;
-    store32<E>(p.out, attn_row(p, seq, i) * (p.heads * 32) + h * 32, o);
+    for (int d = 0; d < D; ++d) o[d] *= inv;
+    store32<E, D>(p.out, attn_row(p, seq, i) * (p.heads * D) + h * D, o);
 }
 
 // ---- long sequences (space attention): block = 256 queries of one (seq, head); K/V tiles of 64
 // keys staged as fp32 in LDS and broadcast-read by every lane.
-template <typename E>
+template <typename E, int D>
 __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float Ks[64][32];
-    __shared__ __attribute__((aligned(16))) float Vs[64][32];
+    __shared__ __attribute__((aligned(16))) float Ks[64][D];
+    __shared__ __attribute__((aligned(16))) float Vs[64][D];
+    constexpr int DP = D >= 32 ? D / 4 : 8;          // dims a staging thread owns (whole 16-byte chunks in either dtype) ...
+    constexpr int NP = D / DP;                       // ... and staging threads per key (4 from D = 32 on)
     const int seq = blockIdx.z, h = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < p.n;
-    const int ld = 3 * p.heads * 32;
-    float q[32], o[32];
+    const int ld = 3 * p.heads * D;
+    float q[D], o[D];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] = 0.f; o[d] = 0.f; }
-    if (active) load32<E>(p.qkv, attn_row(p, seq, i) * ld + h * 32, q);
+    for (int d = 0; d < D; ++d) { q[d] = 0.f; o[d] = 0.f; }
+    if (active) load32<E, D>(p.qkv, attn_row(p, seq, i) * ld + h * D, q);
     float m = -INFINITY, l = 0.f;
-    const float scale = 0.17677669529663687f;
+    constexpr float scale = attn_scale<D>();
     const int klen = p.n_mem + p.n;
     const int key_l = threadIdx.x >> 2, part = threadIdx.x & 3;
     for (int j0 = 0; j0 < klen; j0 += 64) {
         __syncthreads();
-        {   // stage: thread -> (key, 8 dims)
+        if (part < NP) {   // stage: thread -> (key, DP dims)
             const int j = j0 + key_l;
-            float kf[8], vf[8];
+            float kf[DP], vf[DP];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { kf[d] = 0.f; vf[d] = 0.f; }
+            for (int d = 0; d < DP; ++d) { kf[d] = 0.f; vf[d] = 0.f; }
             if (j < klen) {
                 if (j < p.n_mem) {
-                    const float* mk = p.mem_kv + ((int64_t)h * p.n_mem + j) * 32 + part * 8;
-                    const float* mv = p.mem_kv + (((int64_t)p.heads + h) * p.n_mem + j) * 32 + part * 8;
+                    const float* mk = p.mem_kv + ((int64_t)h * p.n_mem + j) * D + part * DP;
+                    const float* mv = p.mem_kv + (((int64_t)p.heads + h) * p.n_mem + j) * D + part * DP;
 #pragma unroll
-                    for (int d = 0; d < 8; ++d) { kf[d] = mk[d]; vf[d] = mv[d]; }
+                    for (int d = 0; d < DP; ++d) { kf[d] = mk[d]; vf[d] = mv[d]; }
                 } else {
                     const int64_t r = attn_row(p, seq, j - p.n_mem) * ld;
-                    const char* kp = (const char*)p.qkv + (r + (p.heads + h) * 32 + part * 8) * E::kBytes;
-                    const char* vp = (const char*)p.qkv + (r + (2 * p.heads + h) * 32 + part * 8) * E::kBytes;
+                    const char* kp = (const char*)p.qkv + (r + (p.heads + h) * D + part * DP) * E::kBytes;
+                    const char* vp = (const char*)p.qkv + (r + (2 * p.heads + h) * D + part * DP) * E::kBytes;
 #pragma unroll
-                    for (int c = 0; c < 8 / E::kVec; ++c) {
+                    for (int c = 0; c < DP / E::kVec; ++c) {
                         Chunk<E>::unpack(*(const i32x4*)(kp + c * 16), kf + c * E::kVec);
                         Chunk<E>::unpack(*(const i32x4*)(vp + c * 16), vf + c * E::kVec);
                     }
                 }
             }
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { Ks[key_l][part * 8 + d] = kf[d]; Vs[key_l][part * 8 + d] = vf[d]; }
+            for (int d = 0; d < DP; ++d) { Ks[key_l][part * DP + d] = kf[d]; Vs[key_l][part * DP + d] = vf[d]; }
         }
         __syncthreads();
         const int jn = min(64, klen - j0);
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
             const int j = j0 + jj;
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) s += q[d] * Ks[jj][d];
+            for (int d = 0; d < D; ++d) s += q[d] * Ks[jj][d];
             s *= scale;
             const bool vis = !p.causal || j < p.n_mem || (j - p.n_mem) <= i;
             if (vis) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
                 const float a = expf(m - mn), e = expf(s - mn);
                 l = l * a + e;
 #pragma unroll
-                for (int d = 0; d < 32; ++d) o[d] = o[d] * a + e * Vs[jj][d];
+                for (int d = 0; d < D; ++d) o[d] = o[d] * a + e * Vs[jj][d];
                 m = mn;
             }
         }
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
     if (active) {
         const float inv = 1.f / l;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) o[d] *= inv;
-        store32<E>(p.out, attn_row(p, seq, i) * (p.heads * 32) + h * 32, o);
+        for (int d = 0; d < D; ++d) o[d] *= inv;
+        store32<E, D>(p.out, attn_row(p, seq, i) * (p.heads * D) + h * D, o);
     }
 }
 
@@ -288,7 +297,7 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
                              int dim_head, int n_mem, int causal, int seq_inner, int64_t seq_outer_stride,
                              int64_t tok_stride, void* stream) {
     if (!qkv || !mem_kv || !out || nseq <= 0 || n <= 0 || heads <= 0 || n_mem < 0 || seq_inner <= 0) return MV2_EINVAL;
-    if (dim_head != 32 || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
+    if ((dim_head != 8 && dim_head != 16 && dim_head != 32 && dim_head != 64) || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
     AttnParams p{qkv, mem_kv, out, nseq, n, heads, n_mem, causal, seq_inner, seq_outer_stride, tok_stride};
     hipStream_t st = (hipStream_t)stream;
 #ifdef MV2_EXPERIMENTS
@@ -296,24 +305,33 @@ extern "C" int mv2_attention(int dtype, const void* qkv, const float* mem_kv, vo
 #else
     constexpr bool no_mfma = false;
 #endif
-    if (dtype == MV2_BF16 && !causal && n >= 64 && !no_mfma) {
+    if (dtype == MV2_BF16 && !causal && n >= 64 && dim_head == 32 && !no_mfma) {
         if (nseq > 65535) return MV2_EINVAL;
         dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)nseq);
         hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), 0, st, p);
         MV2_LAUNCH_CHECK();
         return MV2_OK;
     }
-    if (n < 64) {
-        const int64_t total = (int64_t)nseq * heads * n;
-        const unsigned blocks = (unsigned)((total + 255) / 256);
-        if (dtype == MV2_BF16) hipLaunchKernelGGL((attn_small_kernel<BF16>), dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_small_kernel<F32>), dim3(blocks), dim3(256), 0, st, p);
-    } else {
-        if (nseq > 65535) return MV2_EINVAL;
-        dim3 grid((unsigned)((n + 255) / 256), (unsigned)heads, (unsigned)nseq);
-        if (dtype == MV2_BF16) hipLaunchKernelGGL((attn_tile_kernel<BF16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_tile_kernel<F32>), grid, dim3(256), 0, st, p);
-    }
+    // every other case (fp32, the causal time attention, short sequences, dim_head 8 / 16 / 64) on the VALU kernels
+    if (n >= 64 && nseq > 65535) return MV2_EINVAL;
+#define MV2_ATTN_VALU(Dv)                                                                                                   \
+    do {                                                                                                                    \
+        if (n < 64) {                                                                                                       \
+            const int64_t total = (int64_t)nseq * heads * n;                                                                \
+            const unsigned blocks = (unsigned)((total + 255) / 256);                                                        \
+            if (dtype == MV2_BF16) hipLaunchKernelGGL((attn_small_kernel<BF16, Dv>), dim3(blocks), dim3(256), 0, st, p);    \
+            else hipLaunchKernelGGL((attn_small_kernel<F32, Dv>), dim3(blocks), dim3(256), 0, st, p);                       \
+        } else {                                                                                                            \
+            dim3 grid((unsigned)((n + 255) / 256), (unsigned)heads, (unsigned)nseq);                                        \
+            if (dtype == MV2_BF16) hipLaunchKernelGGL((attn_tile_kernel<BF16, Dv>), grid, dim3(256), 0, st, p);             \
+            else hipLaunchKernelGGL((attn_tile_kernel<F32, Dv>), grid, dim3(256), 0, st, p);                                \
+        }                                                                                                                   \
+    } while (0)
+    if (dim_head == 8) MV2_ATTN_VALU(8);
+    else if (dim_head == 16) MV2_ATTN_VALU(16);
+    else if (dim_head == 32) MV2_ATTN_VALU(32);
+    else MV2_ATTN_VALU(64);
+#undef MV2_ATTN_VALU
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }
@@ -612,6 +630,145 @@ static int taylor_apply_launch(int dtype, const void* q, const float* part, void
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)frames);
     if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_kernel<BF16>), grid, dim3(256), lds, st, q, kvsum, out, n, heads, L);
     else hipLaunchKernelGGL((taylor_apply_kernel<F32>), grid, dim3(256), lds, st, q, kvsum, out, n, heads, L);
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+// ---- any dim_head (4 / 16; 8 has the kernels above): plain VALU kernels for the widths the reference accepts (linear_attn_dim_head is a
+// free keyword, M:1079 -> 415-419) but does not default to.  phi has F = 1 + D + D^2 features, the state per (frame, head) is [F][D + 1]
+// fp32 (column D = the normaliser).  Rows layout only (kv rows [token][k heads x D | v heads x D], q rows [token][heads x D]).
+template <typename E> __device__ __forceinline__ float tay_ld(const void* base, int64_t elem) {
+    if constexpr (E::kBytes == 2) { const unsigned short u = ((const unsigned short*)base)[elem]; return __uint_as_float((unsigned)u << 16); }
+    else return ((const float*)base)[elem];
+}
+template <typename E> __device__ __forceinline__ void tay_st(void* base, int64_t elem, float v) {
+    if constexpr (E::kBytes == 2) ((unsigned short*)base)[elem] = f2bf(v);
+    else ((float*)base)[elem] = v;
+}
+
+// one workgroup per (frame, head): thread t owns the state entries t, t + 256, ... and walks all tokens (staged 64 at a time in LDS)
+template <typename E, int D>
+__global__ __launch_bounds__(256) void taylor_kv_any_kernel(const void* __restrict__ kv, float* __restrict__ state, int n, int heads) {
+    constexpr int F = 1 + D + D * D, W = D + 1, NE = F * W, PER = (NE + 255) / 256, TT = 64;
+    __shared__ float ks[TT][D];
+    __shared__ float vs[TT][W];
+    const int h = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    int ei[PER], ej[PER], ec[PER];
+    float acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = min(tid + 256 * u, NE - 1), feat = e / W;
+        ec[u] = e - feat * W;
+        ei[u] = feat == 0 ? -1 : (feat <= D ? feat - 1 : (feat - 1 - D) / D);
+        ej[u] = feat <= D ? -1 : (feat - 1 - D) % D;
+        acc[u] = 0.f;
+    }
+    const float r2 = 0.70710678118654752440f;
+    const int64_t ld = (int64_t)2 * heads * D;
+    for (int t0 = 0; t0 < n; t0 += TT) {
+        __syncthreads();
+        for (int idx = tid; idx < TT * D; idx += 256) {
+            const int tt = idx / D, d = idx - tt * D, t = t0 + tt;
+            const int64_t row = ((int64_t)f * n + min(t, n - 1)) * ld;
+            const bool live = t < n;
+            ks[tt][d] = live ? tay_ld<E>(kv, row + h * D + d) : 0.f;
+            vs[tt][d] = live ? tay_ld<E>(kv, row + (heads + h) * D + d) : 0.f;
+            if (d == 0) vs[tt][D] = live ? 1.f : 0.f;
+        }
+        __syncthreads();
+        for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const float ph = ei[u] < 0 ? 1.f : (ej[u] < 0 ? ks[tt][ei[u]] : (ks[tt][ei[u]] * ks[tt][ej[u]]) * r2);
+                acc[u] += ph * vs[tt][ec[u]];
+            }
+        }
+    }
+    float* dst = state + ((int64_t)f * heads + h) * NE;
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (tid + 256 * u < NE) dst[tid + 256 * u] = acc[u];
+}
+
+// block = 256 tokens of one (frame, head): the state in LDS (broadcast reads), the scaled query of a thread's token in its own LDS row
+template <typename E, int D>
+__global__ __launch_bounds__(256) void taylor_apply_any_kernel(const void* __restrict__ q, const float* __restrict__ state, void* __restrict__ out,
+                                                               int n, int heads) {
+    constexpr int F = 1 + D + D * D, W = D + 1, NE = F * W;
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float* S = tsm;                 // [F][W]
+    float* qs = tsm + NE;           // [256][D]
+    const int h = blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+    const int tok = blockIdx.x * 256 + tid;
+    const float* src = state + ((int64_t)f * heads + h) * NE;
+    for (int e = tid; e < NE; e += 256) S[e] = src[e];
+    const float scale = D == 4 ? 0.5f : (D == 8 ? 0.35355339059327376220f : 0.25f);          // D^-0.5
+    const int64_t qrow = ((int64_t)f * n + min(tok, n - 1)) * heads * D + h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) qs[tid * D + d] = tay_ld<E>(q, qrow + d) * scale;
+    __syncthreads();
+    const float r2 = 0.70710678118654752440f;
+    float acc[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) acc[e] = S[e];                      // phi_0 = 1
+    for (int i = 0; i < D; ++i) {
+        const float qi = qs[tid * D + i];
+        const float* r = S + (1 + i) * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] += qi * r[e];
+    }
+    for (int i = 0; i < D; ++i) {
+        const float qi = qs[tid * D + i];
+        for (int j = 0; j < D; ++j) {
+            const float ph = (qi * qs[tid * D + j]) * r2;
+            const float* r = S + (1 + D + i * D + j) * W;
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc[e] += ph * r[e];
+        }
+    }
+    if (tok < n) {
+        const float inv = 1.f / fmaxf(acc[D], 1e-5f);
+        const int64_t orow = ((int64_t)f * n + tok) * heads * D + h * D;
+#pragma unroll
+        for (int e = 0; e < D; ++e) tay_st<E>(out, orow + e, acc[e] * inv);
+    }
+}
+
+extern "C" size_t mv2_taylor_state_floats(int dim_head) {
+    return (dim_head == 4 || dim_head == 8 || dim_head == 16) ? (size_t)(1 + dim_head + dim_head * dim_head) * (dim_head + 1) : 0;
+}
+
+extern "C" int mv2_taylor_kv_d(int dtype, const void* kv, float* state, int frames, int n, int heads, int dim_head, void* stream) {
+    if (dim_head == 8) return taylor_kv_launch(dtype, kv, state, frames, n, heads, 1, tay_rows_kv(n, heads), stream);
+    if (!kv || !state || frames <= 0 || n <= 0 || heads <= 0 || frames > 65535) return MV2_EINVAL;
+    if ((dim_head != 4 && dim_head != 16) || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)heads, (unsigned)frames);
+    if (dim_head == 4) {
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_any_kernel<BF16, 4>), grid, dim3(256), 0, st, kv, state, n, heads);
+        else hipLaunchKernelGGL((taylor_kv_any_kernel<F32, 4>), grid, dim3(256), 0, st, kv, state, n, heads);
+    } else {
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_kv_any_kernel<BF16, 16>), grid, dim3(256), 0, st, kv, state, n, heads);
+        else hipLaunchKernelGGL((taylor_kv_any_kernel<F32, 16>), grid, dim3(256), 0, st, kv, state, n, heads);
+    }
+    MV2_LAUNCH_CHECK();
+    return MV2_OK;
+}
+
+extern "C" int mv2_taylor_apply_d(int dtype, const void* q, const float* state, void* out, int frames, int n, int heads, int dim_head, void* stream) {
+    if (dim_head == 8) return taylor_apply_launch(dtype, q, state, out, nullptr, frames, n, heads, 1, tay_rows_q(n, heads), stream);
+    if (!q || !state || !out || frames <= 0 || n <= 0 || heads <= 0 || frames > 65535 || heads > 65535) return MV2_EINVAL;
+    if ((dim_head != 4 && dim_head != 16) || (dtype != MV2_BF16 && dtype != MV2_F32)) return MV2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)heads, (unsigned)frames);
+    const size_t lds = (mv2_taylor_state_floats(dim_head) + (size_t)256 * dim_head) * sizeof(float);
+    if (dim_head == 4) {
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_any_kernel<BF16, 4>), grid, dim3(256), lds, st, q, state, out, n, heads);
+        else hipLaunchKernelGGL((taylor_apply_any_kernel<F32, 4>), grid, dim3(256), lds, st, q, state, out, n, heads);
+    } else {
+        if (dtype == MV2_BF16) hipLaunchKernelGGL((taylor_apply_any_kernel<BF16, 16>), grid, dim3(256), lds, st, q, state, out, n, heads);
+        else hipLaunchKernelGGL((taylor_apply_any_kernel<F32, 16>), grid, dim3(256), lds, st, q, state, out, n, heads);
+    }
     MV2_LAUNCH_CHECK();
     return MV2_OK;
 }

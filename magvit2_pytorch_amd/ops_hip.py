@@ -67,6 +67,9 @@ _SIGS = {
     'mv2_taylor_apply': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_kv_fused': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_taylor_apply_fused': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_taylor_state_floats': (C.c_size_t, [C.c_int]),
+    'mv2_taylor_kv_d': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mv2_taylor_apply_d': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'mv2_lfq': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'mv2_pack_conv3d_bytes': (C.c_size_t, [C.c_int] * 6),
     'mv2_pack_conv3d': (C.c_int, [C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_size_t]),
@@ -358,6 +361,19 @@ class HipOps:
         fn, args = self.lib.mv2_taylor_apply, (dt, _ptr(q), _ptr(part), _ptr(out), _ptr(kvsum), frames, n, heads, nchunk)
         keep = (q, part, out, kvsum)
         return _mk(fn, args, 'mv2_taylor_apply', keep, [out, kvsum] if nchunk > 1 else [out])      # nchunk == 1: kvsum is not written
+
+    def taylor_state_floats(self, dim_head: int) -> int:
+        return int(self.lib.mv2_taylor_state_floats(dim_head))
+
+    def taylor_kv_d(self, dt, kv, state, frames, n, heads, dim_head):
+        fn, args = self.lib.mv2_taylor_kv_d, (dt, _ptr(kv), _ptr(state), frames, n, heads, dim_head)
+        keep = (kv, state)
+        return _mk(fn, args, 'mv2_taylor_kv_d', keep, [state])
+
+    def taylor_apply_d(self, dt, q, state, out, frames, n, heads, dim_head):
+        fn, args = self.lib.mv2_taylor_apply_d, (dt, _ptr(q), _ptr(state), _ptr(out), frames, n, heads, dim_head)
+        keep = (q, state, out)
+        return _mk(fn, args, 'mv2_taylor_apply_d', keep, [out])
 
     def taylor_kv_fused(self, dt, kv, part, frames, n, heads, nchunk):
         fn, args = self.lib.mv2_taylor_kv_fused, (dt, _ptr(kv), _ptr(part), frames, n, heads, nchunk)

@@ -703,6 +703,28 @@ class Plan:
         self.arena.put(x.t)
         return out
 
+    def _linear_attention_any_width(self, steps, pre, x: Act, heads, dh) -> Act:
+        """linear_attn_dim_head 4 / 16 (the reference takes any, M:1079; 8 is its default and has the tuned kernels): to_q and to_kv as two
+        GEMMs in the row layouts, the whole-frame state kernel and the apply kernel at that width (mv2_taylor_kv_d / mv2_taylor_apply_d)."""
+        pm, ops = self.pm, self.ops
+        nfl = ops.taylor_state_floats(dh)
+        if nfl == 0:
+            raise NotImplementedError(f'linear_attn_dim_head={dh}: the Taylor attention kernels are built for 4, 8 or 16')
+        frames, n = x.B * x.T, x.H * x.W
+        q = self._conv(steps, pre + '.q', pm.convs[pre + '.q'], x, rms_shift=False, check_bounds=False)
+        kv = self._conv(steps, pre + '.kv', pm.convs[pre + '.kv'], x, rms_shift=False, check_bounds=False)
+        state = self.arena.get(frames * heads * nfl, torch.float32)
+        o = Act(self.arena.get(x.rows * heads * dh, self.dtype), x.B, x.T, x.H, x.W, heads * dh)
+        steps.append(ops.taylor_kv_d(self.dt, kv.t, state, frames, n, heads, dh))
+        steps.append(ops.taylor_apply_d(self.dt, q.t, state, o.t, frames, n, heads, dh))
+        self.step_names += ['taylor_kv_d', 'taylor_apply_d']
+        for t in (state, q.t, kv.t):
+            self.arena.put(t)
+        out = self._conv(steps, pre + '.out', pm.convs[pre + '.out'], o, residual=x, check_bounds=False)
+        self.arena.put(o.t)
+        self.arena.put(x.t)
+        return out
+
     def _gateloop(self, steps, pre, x: Act) -> Act:
         """'gateloop_time' (reference M:1216-1222; third-party SimpleGateLoopLayer, reconstruction): RMSNorm folded into the Linear
         (gamma * sqrt(dim) in the weights, 1 / |x| as the epilogue rowscale), [q | kv | a] = one pointwise GEMM, then the gated
@@ -719,7 +741,8 @@ class Plan:
     def _linear_attention(self, steps, pre, x: Act) -> Act:
         pm, ops, cfg = self.pm, self.ops, self.cfg
         heads, dh = cfg['linear_attn_heads'], cfg['linear_attn_dim_head']
-        assert dh == 8, 'Taylor attention kernel is built for dim_head 8 (reference default, magvit2_pytorch.py:1079)'
+        if dh != 8:
+            return self._linear_attention_any_width(steps, pre, x, heads, dh)
         frames, n = x.B * x.T, x.H * x.W
         # one workgroup per (frame, head) accumulates the whole frame's state (mv2_taylor_kv with nchunk = 1): no partial states in HBM and no
         # reduce launch.  Only where frames x heads leaves most of the chip idle (single images, one or two frames) does the chunked form

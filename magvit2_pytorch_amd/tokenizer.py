@@ -131,7 +131,10 @@ class VideoTokenizer(nn.Module):
         else:                                                 # reference: magvit2_pytorch.py:1376
             assert not _exists(codebook_size) and _exists(fsq_levels), \
                 'if use_fsq is set to True, `fsq_levels` must be set (and not `codebook_size`)'
-        assert attn_dim_head == 32, 'softmax-attention kernel is built for dim_head 32 (reference default)'
+        if linear_attn_dim_head not in (4, 8, 16):           # reference: any width (magvit2_pytorch.py:1079); 8, its default, has the tuned kernels
+            raise NotImplementedError(f'linear_attn_dim_head={linear_attn_dim_head}: the Taylor attention kernels are built for 4, 8 or 16')
+        if attn_dim_head not in (8, 16, 32, 64):              # reference: any width (magvit2_pytorch.py:1076); 32, its default, is the MFMA kernel's
+            raise NotImplementedError(f'attn_dim_head={attn_dim_head}: the softmax-attention kernels are built for 8, 16, 32 or 64')
 
         self.cfg = S.make_cfg(
             image_size=image_size, layers=tuple(layers), residual_conv_kernel_size=residual_conv_kernel_size,

@@ -168,6 +168,17 @@ FEATURES = {
                                      layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=51, dseed=57),
     'feat_pad_replicate': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, pad_mode='replicate', input_conv_kernel_size=(3, 5, 5),
                                        layers=('residual', 'compress_space', 'compress_time', 'residual', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=51, dseed=57),
+    # attn_dim_head other than the default 32 (reference M:1076 -> 1183, 1202): space attention over 64 tokens + causal time attention
+    'feat_attn_dh16': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, attn_dim_head=16, attn_heads=4,
+                                   layers=('residual', 'compress_space', 'attend_space', 'compress_time', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=71, dseed=72),
+    'feat_attn_dh64': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, attn_dim_head=64, attn_heads=2,
+                                   layers=('residual', 'compress_space', 'attend_space', 'compress_time', 'attend_time')), shape=(2, 3, 5, 16, 16), wseed=73, dseed=74),
+    # linear_attn_dim_head other than the default 8 (reference M:1079 -> 415-419; the Taylor attention itself is the reconstruction of the
+    # un-vendored third-party module, oracle/thirdparty.py: parity unpinned, as for the default width)
+    'feat_linattn_dh16': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, linear_attn_dim_head=16, linear_attn_heads=4,
+                                      layers=('residual', 'compress_space', 'linear_attend_space', 'compress_time', 'residual')), shape=(2, 3, 5, 16, 16), wseed=75, dseed=76),
+    'feat_linattn_dh4': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, linear_attn_dim_head=4, linear_attn_heads=8,
+                                     layers=('residual', 'compress_space', 'linear_attend_space', 'compress_time', 'residual')), shape=(2, 3, 5, 16, 16), wseed=77, dseed=78),
     'feat_sep_loss': dict(kw=dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, separate_first_frame_encoding=True,
                                   layers=('residual', 'compress_space', 'compress_time', 'residual', 'compress_time', 'attend_time')),
                           shape=(2, 3, 9, 16, 16), wseed=4, dseed=1),

@@ -661,6 +661,36 @@ class CpuOps:
         step.what = 'taylor_apply'
         return step
 
+    @staticmethod
+    def taylor_state_floats(d: int) -> int:
+        """mirror of mv2_taylor_state_floats: (1 + d + d^2) features x (d + 1) columns, 0 for a width without kernels"""
+        return (1 + d + d * d) * (d + 1) if d in (4, 8, 16) else 0
+
+    def taylor_kv_d(self, dt, kv, state, frames, n, heads, d):
+        """mv2_taylor_kv_d: the finished state [frames][heads][F][d + 1] at any supported dim_head (rows layout)"""
+        def step(stream):
+            F = 1 + d + d * d
+            KV = kv[: frames * n * 2 * heads * d].reshape(frames, n, 2, heads, d).to(self.acc)
+            k, v = KV[:, :, 0], KV[:, :, 1]
+            v1 = torch.cat((v, v.new_ones(v.shape[:-1] + (1,))), dim=-1)
+            st = torch.einsum('fnhd,fnhe->fhde', self._phi(k), v1).float()
+            state[: frames * heads * F * (d + 1)].copy_(st.reshape(-1))
+        step.outs = [state]
+        step.what = 'taylor_kv_d'
+        return step
+
+    def taylor_apply_d(self, dt, q, state, out, frames, n, heads, d):
+        def step(stream):
+            F = 1 + d + d * d
+            S = state[: frames * heads * F * (d + 1)].reshape(frames, heads, F, d + 1).to(self.acc)
+            qq = q[: frames * n * heads * d].reshape(frames, n, heads, d).to(self.acc) * d ** -0.5
+            acc = torch.einsum('fnhd,fhde->fnhe', self._phi(qq), S)
+            o = acc[..., :d] * (1.0 / acc[..., d:].clamp(min=1e-5))
+            out[: frames * n * heads * d].copy_(o.reshape(-1).to(out.dtype))
+        step.outs = [out]
+        step.what = 'taylor_apply_d'
+        return step
+
     def _qkv_fused(self, qkv, frames, n, heads):
         """head-major fused projection output [frame][head][token][q 8 | k 8 | v 8] -> q, k, v as (f, n, h, 8)"""
         t = qkv[: frames * heads * n * 24].reshape(frames, heads, n, 3, 8).to(self.acc).permute(0, 2, 1, 3, 4)

@@ -92,7 +92,11 @@ def test_abi_rejects_malformed_arguments_without_touching_the_gpu():
     assert lib.mv2_se_pool_fc1(0, ptr, ptr, 0.0, ptr, ptr, ptr, 1, 4, 128, 64, 3, None) == EINVAL   # hidden % nslice != 0
     assert lib.mv2_se_fc2_apply(0, ptr, ptr, ptr, ptr, None, ptr, 1, 4, 96, 48, 1, None) == EINVAL  # C/nslice not a power of 2
     assert lib.mv2_rms_rowscale(0, None, None, 1, 64, 0, 1, None) == EINVAL
-    assert lib.mv2_attention(0, ptr, ptr, ptr, 1, 4, 8, 64, 4, 0, 1, 4, 1, None) == EINVAL      # dim_head must be 32
+    assert lib.mv2_attention(0, ptr, ptr, ptr, 1, 4, 8, 48, 4, 0, 1, 4, 1, None) == EINVAL      # dim_head must be 8, 16, 32 or 64
+    assert lib.mv2_taylor_state_floats(8) == 657 and lib.mv2_taylor_state_floats(16) == 273 * 17 and lib.mv2_taylor_state_floats(4) == 21 * 5
+    assert lib.mv2_taylor_state_floats(32) == 0 and lib.mv2_taylor_state_floats(12) == 0
+    assert lib.mv2_taylor_kv_d(0, ptr, ptr, 1, 4, 8, 12, None) == EINVAL and lib.mv2_taylor_kv_d(0, None, ptr, 1, 4, 8, 16, None) == EINVAL    # width / null
+    assert lib.mv2_taylor_apply_d(0, ptr, ptr, ptr, 1, 4, 8, 32, None) == EINVAL and lib.mv2_taylor_apply_d(2, ptr, ptr, ptr, 1, 4, 8, 16, None) == EINVAL   # width / dtype
     assert lib.mv2_lfq(0, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, 1, 64, 17, 2, 10.0, 1.0, None) == EINVAL   # 34 code dims > 32
     assert lib.mv2_fsq_codes(0, None, None, None, None, None, None, None, 1, 64, 4, 1, None) == EINVAL
     assert lib.mv2_taylor_kv(0, ptr, ptr, 1, 4, 16, 8, None) == EINVAL                          # more chunks than tokens
@@ -657,7 +661,7 @@ def test_facade_vs_reference_feature_fixtures():
             total, br = tok(f.video(), return_loss=True)
             assert abs(float(total) - f.scalar(f'{mode}_total')) <= 1e-5 * max(1., abs(f.scalar(f'{mode}_total'))), (name, mode)
             assert abs(float(br.lfq_aux_loss) - f.scalar(f'{mode}_aux')) <= 1e-5
-    for name in ('feat_cond_residual', 'feat_sep_first_frame', 'feat_pad_reflect', 'feat_pad_replicate'):
+    for name in ('feat_cond_residual', 'feat_sep_first_frame', 'feat_pad_reflect', 'feat_pad_replicate', 'feat_attn_dh16', 'feat_attn_dh64', 'feat_linattn_dh16', 'feat_linattn_dh4'):
         f = Feature(name)
         tok = emulated_tokenizer(dict(f.kw, use_gan=False), f.weights(), torch.float32)
         ckw = dict(cond=f.cond()) if f.cond() is not None else {}

@@ -241,7 +241,7 @@ def test_product_vs_reference_feature_fixtures():
             assert abs(float(total) - f.scalar(f'{mode}_total')) <= 3e-4 * max(1., abs(f.scalar(f'{mode}_total'))), (name, mode)
             assert abs(float(br.recon_loss) - f.scalar(f'{mode}_recon')) <= 1e-4 * f.scalar(f'{mode}_recon')
             assert abs(float(br.lfq_aux_loss) - f.scalar(f'{mode}_aux')) <= 2e-4
-    for name in ('feat_cond_residual', 'feat_sep_first_frame'):
+    for name in ('feat_cond_residual', 'feat_sep_first_frame', 'feat_attn_dh16', 'feat_attn_dh64', 'feat_linattn_dh16', 'feat_linattn_dh4'):      # attn_dim_head 16 / 64, linear_attn_dim_head 16 / 4 (round 6)
         f = Feature(name)
         tok = VideoTokenizer(**f.kw, use_gan=False, seed=0)
         tok.load_state_dict(f.weights())

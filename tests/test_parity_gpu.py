@@ -176,6 +176,101 @@ def test_lockstep_full_channel_widths(dtype):
     run_lockstep(cfg, sd, v, dtype)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dh,heads', [(8, 8), (16, 4), (64, 2)])
+def test_lockstep_attention_head_widths(dh, heads, dtype):
+    """attn_dim_head other than the reference's default 32 (it takes any: magvit2_pytorch.py:1076 -> 1183, 1202): the VALU attention
+    kernels are templated on the width (8 / 16 / 32 / 64; the MFMA kernel stays 32-only).  Space attention over 256 tokens (tile kernel),
+    causal time attention over 5 and 3 frames (small kernel), launch by launch against the emulation; in fp32 also end to end against the
+    restated reference.  The reference's own outputs at widths 16 and 64: tests/golden/feat_attn_dh*.npz (test_losses_gpu.py)."""
+    kw = dict(image_size=32, init_dim=32, max_dim=64, codebook_size=256, attn_dim_head=dh, attn_heads=heads,
+              layers=('residual', 'compress_space', 'attend_space', 'attend_time', 'compress_time', 'attend_time'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=80 + dh, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(81 + dh))
+    run_lockstep(cfg, sd, v, dtype)
+    tok = hip_tokenizer(kw, sd, dtype)
+    orc = OracleTokenizer(sd, **cfg)
+    orc.taps = {}
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    codes, recon = tok(v.cuda(), return_codes=True, return_recon=True)
+    if dtype == torch.float32:
+        margin_check(codes, ocodes, orc.taps['prequant'], 1e-4, 0.005)
+        if torch.equal(codes.cpu(), ocodes):
+            assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
+    else:
+        assert (codes.cpu() != ocodes).float().mean().item() <= 0.04
+        assert (recon.cpu() - orecon).abs().mean().item() <= 1.5e-2
+    assert torch.equal(tok.decode_from_code_indices(codes), recon)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dh,heads', [(4, 8), (16, 4)])
+def test_lockstep_linear_attention_head_widths(dh, heads, dtype):
+    """linear_attn_dim_head other than the reference's default 8 (a free keyword there: magvit2_pytorch.py:1079 -> 415-419): the generic
+    Taylor kernels (mv2_taylor_kv_d / mv2_taylor_apply_d: F = 1 + d + d^2 features, state [F][d + 1]) launch by launch against the emulation
+    and, in fp32, end to end against the restated reference.  The reference's own outputs: tests/golden/feat_linattn_dh*.npz."""
+    kw = dict(image_size=32, init_dim=32, max_dim=64, codebook_size=256, linear_attn_dim_head=dh, linear_attn_heads=heads,
+              layers=('residual', 'compress_space', 'linear_attend_space', 'compress_time', 'residual', 'linear_attend_space'))
+    cfg = make_cfg(**kw)
+    sd = init_state_dict(cfg, seed=90 + dh, randomize_se=True)
+    v = torch.randn(2, 3, 5, 32, 32, generator=torch.Generator().manual_seed(91 + dh))
+    run_lockstep(cfg, sd, v, dtype)
+    tok = hip_tokenizer(kw, sd, dtype)
+    orc = OracleTokenizer(sd, **cfg)
+    orc.taps = {}
+    ocodes, orecon = orc(v, return_codes=True, return_recon=True)
+    codes, recon = tok(v.cuda(), return_codes=True, return_recon=True)
+    if dtype == torch.float32:
+        margin_check(codes, ocodes, orc.taps['prequant'], 1e-4, 0.005)
+        if torch.equal(codes.cpu(), ocodes):
+            assert (recon.cpu() - orecon).abs().max().item() <= 5e-4
+    else:
+        assert (codes.cpu() != ocodes).float().mean().item() <= 0.04
+        assert (recon.cpu() - orecon).abs().mean().item() <= 1.5e-2
+    assert torch.equal(tok.decode_from_code_indices(codes), recon)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('d,heads,frames,n', [(4, 8, 3, 70), (16, 4, 2, 300), (16, 16, 5, 64), (8, 16, 3, 133)])
+def test_taylor_any_width_kernels_vs_emulation(d, heads, frames, n, dtype):
+    """mv2_taylor_kv_d / mv2_taylor_apply_d through the ABI on ragged token counts (tail tiles of the 64-token staging and of the 256-token
+    apply blocks); d = 8 forwards to the tuned kernels and must agree with the same emulation."""
+    from magvit2_pytorch_amd import pack as PK
+    from magvit2_pytorch_amd.ops_hip import HipOps
+    ops, cpu = HipOps('cuda:0'), CpuOps()
+    g = torch.Generator().manual_seed(d * 100 + n)
+    dt = PK.dtype_code(dtype)
+    nfl = ops.taylor_state_floats(d)
+    assert nfl == cpu.taylor_state_floats(d) == (1 + d + d * d) * (d + 1) and ops.taylor_state_floats(12) == 0
+    kv = (torch.randn(frames * n * 2 * heads * d, generator=g) * 0.7).to(dtype)
+    q = (torch.randn(frames * n * heads * d, generator=g) * 0.7).to(dtype)
+    st_c, st_g = torch.zeros(frames * heads * nfl), torch.zeros(frames * heads * nfl, device='cuda')
+    out_c, out_g = torch.zeros(frames * n * heads * d, dtype=dtype), torch.zeros(frames * n * heads * d, dtype=dtype, device='cuda')
+    cpu.taylor_kv_d(dt, kv, st_c, frames, n, heads, d)(None)
+    cpu.taylor_apply_d(dt, q, st_c, out_c, frames, n, heads, d)(None)
+    kvg, qg = kv.cuda(), q.cuda()
+    ops.taylor_kv_d(dt, kvg, st_g, frames, n, heads, d)(ops.current_stream())
+    ops.taylor_apply_d(dt, qg, st_g, out_g, frames, n, heads, d)(ops.current_stream())
+    ops.synchronize()
+    assert torch.allclose(st_g.cpu(), st_c, rtol=2e-4, atol=2e-4 * st_c.abs().max().item())
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(out_g.cpu().float(), out_c.float(), rtol=tol, atol=tol)
+
+
+def test_attention_rejects_unsupported_head_width():
+    """widths the kernels are not built for raise at construction (NotImplementedError) and at the ABI (MV2_EINVAL)"""
+    from magvit2_pytorch_amd.ops_hip import HipOps, Mv2Error
+    with pytest.raises(NotImplementedError):
+        VideoTokenizer(image_size=16, init_dim=16, max_dim=32, codebook_size=64, attn_dim_head=24, layers=('residual', 'attend_space'))
+    with pytest.raises(NotImplementedError):
+        VideoTokenizer(image_size=16, init_dim=16, max_dim=32, codebook_size=64, linear_attn_dim_head=32, layers=('residual', 'linear_attend_space'))
+    ops = HipOps('cuda:0')
+    x = torch.zeros(64 * 3 * 2 * 24, device='cuda')
+    with pytest.raises(Mv2Error):
+        ops.attention(1, x, torch.zeros(2, 2, 4, 24, device='cuda'), torch.zeros(64 * 2 * 24, device='cuda'), 1, 64, 2, 24, 4, False, 1, 64, 1)(ops.current_stream())
+
+
 @pytest.mark.parametrize('case', [0, 2, 3])
 def test_lockstep_split_mode(case):
     """The id-exact 'split' plan (fp32 storage, ResidualUnit convolutions as mv2_split_bf16 + mv2_conv3 with MV2_STORE_ROWS_F32) launch by
