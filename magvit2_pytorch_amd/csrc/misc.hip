@@ -45,8 +45,8 @@ extern "C" int mv2_video_to_ndhwc(int dtype, const float* in, void* out, int B, 
 }
 
 // --------------------------------------------------------------------------- RMSNorm statistics
-// G lanes cooperate on one row (G = min(64, chunks per row), power of two); lane reads chunks
-// lane, lane+G, ... ; sum of squares reduced with xor shuffles inside the group.
+// G lanes cooperate on one row (G = min(64, chunks per row rounded up to a power of two)); lane reads chunks
+// lane, lane+G, ... (any chunk count); sum of squares reduced with xor shuffles inside the group.
 template <typename E>
 __global__ __launch_bounds__(256) void rms_rowscale_kernel(const void* __restrict__ x, float* __restrict__ rs, int64_t rows,
                                                            int C, int G, int shift_hw, int T) {
@@ -109,8 +109,8 @@ extern "C" int mv2_rms_rowscale(int dtype, const void* x, float* rowscale, int64
     const int kvec = dtype == MV2_BF16 ? 8 : 4;
     if (C % kvec != 0 || (shift_hw > 0 && (C / 2) % kvec != 0)) return MV2_EINVAL;
     const int nchunk = C / kvec;
-    int G = nchunk >= 64 ? 64 : nchunk;
-    if (!is_pow2(G) || (nchunk > 64 && nchunk % 64 != 0)) return MV2_EINVAL;
+    int G = 64;
+    if (nchunk < 64) { G = 1; while (G < nchunk) G <<= 1; }      // next power of two: lanes >= nchunk find no chunk and add 0 (round 6: any width)
     const int rpb = 256 / G;
     int64_t blocks = (rows + rpb - 1) / rpb; if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;

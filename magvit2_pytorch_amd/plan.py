@@ -81,8 +81,8 @@ class PackedModel:
         self.stages: List[Stage] = parse_layers(cfg['layers'], cfg['init_dim'], cfg['max_dim'])
         # 4-channel pixels: 8-byte (bf16) / 16-byte (fp32) rows; 16-byte gathers at 8-byte alignment verified on gfx950
         self.c_in_pad = OPTIONS.convin_cpad
-        if cfg['channels'] > self.c_in_pad:          # 5 .. 8 input channels: 8-channel pixels (16 bytes in bf16, the round-1 layout)
-            self.c_in_pad = 8
+        if cfg['channels'] > self.c_in_pad:          # 5 .. 64 input channels: pixels of 8, 16, ... channels (whole 16-byte chunks in bf16; 8 = the round-1 layout)
+            self.c_in_pad = (cfg['channels'] + 7) // 8 * 8
         f = lambda k: sd[k].detach().float().cpu()
         dev = ops.to_device
         self.convs: Dict[str, P.PackedConv] = {}

@@ -222,18 +222,20 @@ class VideoTokenizer(nn.Module):
 
     @staticmethod
     def _validate_widths(channels, stages):
-        """Channel widths the kernels support: conv_in packs <= 8 input channels per pixel (4-channel pixels up to 4 channels,
-        8-channel pixels above; the image discriminator reads 4-channel pixels, so use_gan needs channels <= 4); rows are moved in
-        16-byte chunks (8 bf16), RMSNorm / TokenShift kernels split rows into power-of-two lane groups."""
-        if channels > 8:
-            raise NotImplementedError(f'channels={channels}: the input convolution packs at most 8 channels per pixel')
+        """Channel widths the kernels support: input pixels travel as 4 channels (up to 4) or as the next multiple of 8 channels
+        (5 .. 64; the image discriminator reads 4-channel pixels, so use_gan needs channels <= 4); rows are moved in
+        16-byte chunks (8 bf16), TokenShift moves half rows in such chunks, the gated scan splits rows into power-of-two lane groups."""
+        if channels > 64:
+            raise NotImplementedError(f'channels={channels}: the input convolution packs at most 64 channels per pixel')
         pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
         for st in stages:
             for dim in {st.dim, st.dim_out}:
                 if dim % 8 != 0:
                     raise NotImplementedError(f'layer width {dim} ({st.kind}): widths must be multiples of 8 (16-byte bf16 chunks)')
-            if st.kind in ('attend_space', 'attend_time', 'linear_attend_space', 'gateloop_time') and not pow2(st.dim):
-                raise NotImplementedError(f'{st.kind} at width {st.dim}: the RMSNorm / TokenShift kernels need a power-of-two width')
+            if st.kind == 'gateloop_time' and not pow2(st.dim):
+                raise NotImplementedError(f'{st.kind} at width {st.dim}: the gated-scan kernel needs a power-of-two width')
+            if st.kind in ('attend_time', 'cond_attend_time') and st.dim % 16 != 0 and not pow2(st.dim):
+                raise NotImplementedError(f'{st.kind} at width {st.dim}: TokenShift moves half rows in 16-byte chunks (width % 16 == 0, or 8)')
 
     # ------------------------------------------------------------------ weights
     @property

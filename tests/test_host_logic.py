@@ -365,14 +365,15 @@ def test_squeeze_excite_forms_agree(monkeypatch):
 def test_unsupported_widths_are_rejected_at_construction():
     """widths the kernels cannot run must fail in the constructor with a clear message, not as an opaque
     error code at the first forward."""
-    for bad in (dict(channels=9), dict(channels=5, use_gan=True), dict(init_dim=12), dict(init_dim=24, layers=('attend_space',))):
+    for bad in (dict(channels=65), dict(channels=5, use_gan=True), dict(init_dim=12), dict(init_dim=24, layers=('attend_time',)), dict(init_dim=24, layers=('gateloop_time',)),
+                dict(attn_dim_head=24), dict(linear_attn_dim_head=32)):
         with pytest.raises(NotImplementedError):
             VideoTokenizer(image_size=32, codebook_size=256, **{**dict(init_dim=8, max_dim=64, layers=README_LAYERS, use_gan=False), **bad})
 
 
-@pytest.mark.parametrize('channels', [1, 4, 5, 8])
+@pytest.mark.parametrize('channels', [1, 4, 5, 8, 12, 20])
 def test_input_channel_counts_match_oracle(channels):
-    """1 .. 4 channels travel as 4-channel pixels, 5 .. 8 as 8-channel pixels (conv_in's (iw, c) K extent); conv_out stores `channels` planes."""
+    """1 .. 4 channels travel as 4-channel pixels, 5 .. 64 as pixels of the next multiple of 8 channels (conv_in's (iw, c) K extent); conv_out stores `channels` planes."""
     kw = dict(image_size=16, init_dim=16, max_dim=32, codebook_size=64, channels=channels, input_conv_kernel_size=(3, 5, 5),
               layers=('residual', 'compress_space', 'compress_time', 'residual'))
     cfg = make_cfg(**kw)

@@ -990,6 +990,13 @@ ODD_CASES = [
                  layers=('residual', 'compress_time', 'residual', 'compress_space', 'compress_time', 'residual', 'linear_attend_space')), B=1, T=17),
     # width that is not a power of two in the residual stack (no attention layers: C = 96 / 192)
     dict(kw=dict(image_size=32, init_dim=96, max_dim=192, codebook_size=256, layers=('residual', 'compress_space', 'residual', 'compress_time', 'residual')), B=2, T=5),
+    # attention layers at widths that are not powers of two (round 6: RMSNorm's row groups mask the lanes past the row): 48 -> 96 with space,
+    # linear and (token-shifted, causal) time attention and their feed-forwards
+    dict(kw=dict(image_size=32, init_dim=48, max_dim=96, codebook_size=256, attn_heads=4,
+                 layers=('residual', 'compress_space', 'attend_space', 'linear_attend_space', 'compress_time', 'attend_time')), B=2, T=5),
+    # ... and 24 -> 48 -> 96 -> 192 (48: rows of 96 bytes; 192 on the deep levels)
+    dict(kw=dict(image_size=32, init_dim=24, max_dim=192, codebook_size=64, attn_heads=2, linear_attn_heads=4,
+                 layers=('linear_attend_space', 'compress_space', 'attend_space', 'compress_space', 'attend_time', 'compress_space', 'attend_space')), B=1, T=5),
 ]
 
 

@@ -130,7 +130,7 @@ def test_tokenize_stream_on_gpu(depth):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('channels', [1, 5, 8])
+@pytest.mark.parametrize('channels', [1, 5, 8, 12, 20])
 def test_input_channel_counts_lockstep(channels, dtype):
     """8-channel input pixels (5 .. 8 channels): the round-1 conv_in layout, not exercised by the default suite of round 2"""
     kw = dict(image_size=32, init_dim=16, max_dim=64, codebook_size=256, channels=channels, layers=('residual', 'compress_space', 'compress_time', 'residual'))
