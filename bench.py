@@ -337,7 +337,7 @@ def _main(args, lowering):
         # HBM-side bytes per conv3 launch: from the committed rocprofv3 --pmc passes of THIS command (not collectable in-process).  The file is
         # stamped with a hash of the kernel sources it was measured on; a stale file is not printed.
         traffic, traffic_source = None, None
-        for tag in ('r06c', 'r06', 'r05', 'r04'):
+        for tag in ('r06g', 'r06c', 'r06', 'r05', 'r04'):
             tf = os.path.join(ROOT, 'profiles', f'{tag}_traffic.json')
             if not (os.path.exists(tf) and args.dtype == 'bf16' and B == 1 and cfg_id == 1):
                 continue
@@ -366,7 +366,7 @@ def _main(args, lowering):
                         achieved_executed=c3['achieved_executed'], frac_executed=c3['frac_executed'], traffic=traffic,
                         traffic_source=traffic_source, launches=c3['launches'], flops_per_launch=c3['flops_per_launch'],
                         avg_launch_ms=c3['avg_launch_ms'],
-                        avg_launch_authority='profiles/r06c_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
+                        avg_launch_authority='profiles/r06g_rocprofv3_kernel_stats_bench_b1.csv (rocprofv3 --kernel-trace --stats of this command); '
                                              'the in-process figure issues every launch 5x back to back between two HIP events (L2/MALL-warm repeats: '
                                              'short launches read warm operands; cold per-launch figures are in the rocprofv3 csv and tools/k3_bench logs)',
                         encode_path=encode_path,
